@@ -1,0 +1,193 @@
+/*
+ * vr.h -- C ABI of the MI355X-native volume ray-marcher (libvr_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of gutiKristian/VolumeRendering:
+ * the per-pixel front-to-back compositing loop that the reference runs as WGSL
+ * fragment shaders (App/shaders/{...}.wgsl `fs_main`) behind WebGPU/Dawn.  The reference
+ * has no FFI of its own; what it has is a bind-group contract between
+ * `Application::OnUpdate/OnRender` and the shaders.  Every entry point below cites the
+ * reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns VR_OK (0) or a negative
+ *     vr_status; the message for the last failure is available via vr_last_error().
+ *     No exception crosses this boundary.  (The reference only logs / asserts:
+ *     WebgpuLib/src/Platform/Native/NativeGraphicsContext.cpp:102-116.)
+ *   - a vr_ctx is bound to ONE HIP device (one process per GPU) and must be used by one
+ *     thread at a time (the reference is single threaded, App/src/Application.cpp:332-379).
+ *   - host pointers are copied at call time; the caller keeps ownership, exactly like
+ *     wgpuQueueWriteTexture / wgpuQueueWriteBuffer (App/src/renderer/Texture.cpp:80,
+ *     App/src/renderer/UniformBuffer.cpp:27).
+ *   - all matrices are column-major float[16] (glm layout, App/src/Application.cpp:102-105).
+ *   - there is NO CPU fallback behind this ABI: if no HIP device is usable vr_create
+ *     fails with VR_ERR_HIP.
+ */
+#ifndef VR_H_
+#define VR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_ABI_VERSION 1
+
+typedef enum vr_status {
+    VR_OK = 0,
+    VR_ERR_INVALID_ARG = -1,  /* null pointer, bad slot / variant / size                    */
+    VR_ERR_HIP = -2,          /* a HIP runtime call failed (message has hipGetErrorString)   */
+    VR_ERR_NOT_READY = -3,    /* render called before the volumes / TFs the variant needs    */
+    VR_ERR_UNSUPPORTED = -4,  /* e.g. non-identity model matrix (see vr_set_uniforms)        */
+    VR_ERR_OOM = -5
+} vr_status;
+
+/* One value per live fragment shader of the reference. */
+typedef enum vr_variant {
+    VR_VARIANT_BASIC = 0,       /* App/shaders/BasicVolumeApp.wgsl:113-188   unlit, cut-off dst.a <= 0.95 */
+    VR_VARIANT_LIGHT = 1,       /* App/shaders/BasicVolLightApp.wgsl:151-237 lit,   cut-off dst.a <  1.0  */
+    VR_VARIANT_VOLUME_MASK = 2, /* App/shaders/VolumeMaskApp.wgsl:128-217    mask + RT + CT               */
+    VR_VARIANT_THREE_FILES = 3, /* App/shaders/ThreeFilesApp.wgsl:170-272    CT/RT colour mix             */
+    VR_VARIANT_MULTI_CTRT = 4,  /* App/shaders/MultiCTRTApp.wgsl:163-259     CT/RT mix + shade + |g| opacity */
+    VR_VARIANT_TF_CALIB = 5,    /* App/shaders/TFCalibrationApp.wgsl:114-197 CT + nearest-sampled mask     */
+    VR_VARIANT_COUNT = 6
+} vr_variant;
+
+#define VR_MAX_VOLUMES 3
+#define VR_MAX_TFS 2
+
+/*
+ * Volume slots = the order of the texture_3d bindings in the scene's @group(1):
+ *   BASIC / LIGHT : 0 = volume                      (BasicVolLightApp.wgsl:50)
+ *   VOLUME_MASK   : 0 = mask, 1 = RT dose, 2 = CT   (VolumeMaskApp.wgsl:40-42)
+ *   THREE_FILES   : 0 = CT, 1 = RT, 2 = mask (bound, never sampled) (ThreeFilesApp.wgsl:50-52)
+ *   MULTI_CTRT    : 0 = CT, 1 = RT                  (MultiCTRTApp.wgsl:50-51)
+ *   TF_CALIB      : 0 = CT, 1 = mask                (TFCalibrationApp.wgsl:40-41)
+ * TF slots = the order of the (opacity, colour) texture_1d pairs:
+ *   single-TF scenes: 0;  two-TF scenes: 0 = CT pair, 1 = RT pair (VolumeMaskApp.wgsl:43-46).
+ */
+
+/*
+ * The uniform block.  Fields 1:1 with @group(0) of every shader
+ * (App/shaders/BasicVolumeApp.wgsl:26-37, filled by App/src/Application.cpp:544-556 and
+ * rewritten every frame by Application::OnUpdate, App/src/Application.cpp:96-119), followed
+ * by the per-scene `Light` (App/src/renderer/Light.h:9-14 <-> BasicVolLightApp.wgsl:25-33).
+ */
+typedef struct vr_uniforms {
+    float model[16];      /* binding 0 @0   : must be identity (Application.cpp:489-492 never rewrites it) */
+    float view[16];       /* binding 0 @64  : Camera::GetViewMatrix              */
+    float proj[16];       /* binding 0 @128 : Camera::GetProjectionMatrix        */
+    float view_inv[16];   /* binding 0 @192 : Camera::GetInverseViewMatrix       */
+    float proj_inv[16];   /* binding 0 @256 : Camera::GetInverseProjectionMatrix */
+    float camera_pos[3];  /* binding 1      : Camera::GetPosition                */
+    int32_t fragment_mode;/* binding 4      : 0 volume, 1 |dir|, 2 start, 3 end, 4 screen uv (Application.h:191-198) */
+    int32_t steps_count;  /* binding 5 */
+    float step_size;      /* binding 6 */
+    float clip_x[2];      /* binding 7 */
+    float clip_y[2];      /* binding 8 */
+    float clip_z[2];      /* binding 9 */
+    int32_t toggles[4];   /* binding 10: [0] variable step, [1] jitter, [2],[3] unused */
+    float light_pos[4];   /* Light.Position */
+    float light_ambient[4];
+    float light_diffuse[4];
+} vr_uniforms;
+
+typedef struct vr_ctx vr_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* Replaces: base::Window + GraphicsContext::Init + Application::Initialize{Uniforms,Textures,
+ * BindGroups,RenderPipelines} (App/src/Application.cpp:58-94, 475-615).  width x height is the
+ * viewport (reference default 1280x720, Application.h:100-101).  device_id = HIP ordinal.      */
+int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id);
+
+/* Replaces: Application::OnResize (Application.cpp:299-323) -- re-creates the per-pixel buffers. */
+int vr_resize(vr_ctx* ctx, uint32_t width, uint32_t height);
+
+void vr_destroy(vr_ctx* ctx);
+
+/* Message of the last failing call on this ctx (ctx may be NULL: last vr_create failure). */
+const char* vr_last_error(const vr_ctx* ctx);
+
+int vr_abi_version(void);
+
+/* ---- scene resources ------------------------------------------------------------------ */
+
+/* Replaces: Texture::CreateFromData(..., WGPUTextureDimension_3D, size, RGBA32Float, ...)
+ * (App/src/renderer/Texture.cpp:34-85) called from every MiniApp::OnStart, e.g.
+ * App/src/miniapps/BasicVolLightApp.cpp:39-40.  `vec4_voxels` is VolumeFile::GetVoidPtr():
+ * nx*ny*nz glm::vec4, x fastest, index z*ny*nx + y*nx + x (VolumeFile.cpp:306), .rgb = gradient
+ * (or the raw value), .a = density.                                                             */
+int vr_volume_upload(vr_ctx* ctx, int slot, const float* vec4_voxels, uint16_t nx, uint16_t ny, uint16_t nz);
+
+/* Same, from a DEVICE pointer that already holds the vec4 voxels (no host round trip). */
+int vr_volume_upload_device(vr_ctx* ctx, int slot, const void* d_vec4_voxels, uint16_t nx, uint16_t ny, uint16_t nz);
+
+/* Replaces: OpacityTF / ColorTF texture creation and TransferFunction::UpdateTexture
+ * (App/src/tf/OpacityTf.cpp:25-26,134-142; App/src/tf/ColorTf.cpp:23-24).  opacity: R floats
+ * (R32Float 1-D), color_rgba: 4R floats (RGBA32Float 1-D).                                       */
+int vr_tf_upload(vr_ctx* ctx, int slot, const float* opacity, const float* color_rgba, uint32_t resolution);
+
+/* Replaces: the 12 wgpuQueueWriteBuffer calls of Application::OnUpdate (Application.cpp:96-119)
+ * plus the scene's Light uniform (BasicVolLightApp.cpp:42).  Returns VR_ERR_UNSUPPORTED when
+ * `model` is not the identity (the reference never uploads anything else).                       */
+int vr_set_uniforms(vr_ctx* ctx, const vr_uniforms* u);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+
+/* Replaces: the "ray end" pass + the volume pass of Application::OnRender
+ * (Application.cpp:150-220): analytic ray/box set-up (rayCoords.wgsl + rasteriser) and the
+ * fs_main compositing loop of the chosen shader, for every pixel.  Synchronous on return.       */
+int vr_render(vr_ctx* ctx, int variant);
+
+/* Image-tile partition (multi-GPU, one process per GPU): renders only the 64x64 screen tiles t
+ * with (t % world) == rank, t = ty * tiles_x + tx, and stores them packed, tile after tile in
+ * increasing t, each tile as 64*64 RGBA32F row-major (pixels outside the viewport = 0).
+ * The packed buffer is `vr_tile_count(ctx, rank, world) * 64*64*4` floats.                       */
+int vr_render_tiles(vr_ctx* ctx, int variant, int rank, int world);
+int vr_tile_count(const vr_ctx* ctx, int rank, int world);
+
+/* Asynchronous forms: enqueue on `stream` (a hipStream_t, NULL = the ctx's own stream) and write
+ * to DEVICE memory supplied by the caller; nothing is synchronised.  `d_frame` = W*H*4 floats;
+ * `d_tiles` as described above.  These are what a multi-rank host (RCCL gather) drives.          */
+int vr_render_async(vr_ctx* ctx, int variant, void* d_frame, void* stream);
+int vr_render_tiles_async(vr_ctx* ctx, int variant, int rank, int world, void* d_tiles, void* stream);
+
+/* Root side of the gather: `d_gathered` holds, for r = 0..world-1, rank r's packed tiles, each
+ * rank's segment padded to `tiles_per_rank_max * 64*64*4` floats; scatters them back into the
+ * W*H*4 frame `d_frame` (device).                                                                */
+int vr_unpack_tiles_async(vr_ctx* ctx, const void* d_gathered, int world, void* d_frame, void* stream);
+
+/* Replaces: reading back the colour attachment.  frag_rgba (W*H*4 floats, may be NULL) receives
+ * the fragment shader output `dst` per pixel BEFORE output merge; pixels with no fragment = 0.
+ * present_bgra8 (W*H*4 bytes, may be NULL) receives the presented pixel: blend
+ * SrcAlpha/OneMinusSrcAlpha over the white background quad, BGRA8Unorm
+ * (App/src/renderer/PipelineBuilder.cpp:142-147, App/shaders/fullscreen.wgsl:33-41,
+ * NativeGraphicsContext.cpp:118).  composited_samples (may be NULL) = number of loop iterations
+ * whose blend executed, summed over the pixels rendered by the last render call.                 */
+int vr_download(vr_ctx* ctx, float* frag_rgba, uint8_t* present_bgra8, uint64_t* composited_samples);
+
+/* Packed tiles of the last vr_render_tiles (host copy). */
+int vr_download_tiles(vr_ctx* ctx, float* tiles_rgba, uint64_t* composited_samples);
+
+/* ---- instrumentation ------------------------------------------------------------------ */
+
+/* HIP-event time of the last render's march kernel and of the whole render call (ray set-up,
+ * march, counters), in milliseconds; valid after a synchronous render or after the caller
+ * synchronised the stream.  Replaces the FPS / frame-time read-out (Application.cpp:339-370).    */
+int vr_last_timing(vr_ctx* ctx, float* kernel_ms, float* total_ms);
+
+/* Device pointer of the ctx-owned frame buffer (W*H*4 floats) written by vr_render. */
+void* vr_frame_device_ptr(vr_ctx* ctx);
+
+/* Number of pixels that produced a fragment in the last render (front face hit & not clipped). */
+int vr_last_covered_pixels(vr_ctx* ctx, uint64_t* covered);
+
+/* Kernel flavour for A/B measurements: 0 = default (best), >0 = named alternatives listed in
+ * DESIGN.md.  All flavours are bit-identical in output.                                          */
+int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR_H_ */

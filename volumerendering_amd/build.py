@@ -1,0 +1,56 @@
+"""Builds the in-tree native libraries: libvr_hip.so (HIP kernels + C ABI, gfx950) and libvr_host.so
+(C++ host surface mirroring the reference's Volume / TransferFunction / Camera / MiniApp classes)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+             "-std=c++17", "-Wall", "-Wno-unused-function"]
+HOST_FLAGS = ["-O2", "-std=c++20", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall"]
+
+
+def _newer(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _sources(d: str, exts: tuple[str, ...]) -> list[str]:
+    out = []
+    for dp, _, fs in os.walk(d):
+        out += [os.path.join(dp, f) for f in fs if f.endswith(exts)]
+    return sorted(out)
+
+
+def build_hip(force: bool = False) -> str:
+    target = os.path.join(HERE, "libvr_hip.so")
+    deps = [os.path.join(CSRC, f) for f in ("vr_api.hip", "vr_kernels.h", "vr_device.h")]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "vr.h"))
+    if force or _newer(target, deps):
+        subprocess.run([HIPCC, *HIP_FLAGS, "-o", target, os.path.join(CSRC, "vr_api.hip")], check=True)
+    return target
+
+
+def build_host(force: bool = False) -> str | None:
+    hostdir = os.path.join(CSRC, "host")
+    cpps = _sources(hostdir, (".cpp",))
+    if not cpps:
+        return None
+    target = os.path.join(HERE, "libvr_host.so")
+    deps = _sources(hostdir, (".cpp", ".h")) + [os.path.join(os.path.dirname(HERE), "include", "vr.h")]
+    if force or _newer(target, deps):
+        subprocess.run(["g++", *HOST_FLAGS, "-I", os.path.join(os.path.dirname(HERE), "include"), "-o", target, *cpps,
+                        "-L", HERE, "-lvr_hip", "-Wl,-rpath,$ORIGIN"], check=True)
+    return target
+
+
+def build_all(force: bool = False):
+    build_hip(force)
+    build_host(force)

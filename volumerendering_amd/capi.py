@@ -1,0 +1,209 @@
+"""ctypes binding of the C ABI in include/vr.h (libvr_hip.so).
+
+Plumbing only: the product is the HIP library.  There is no CPU fallback -- if the shared library is missing
+or no HIP device can be opened, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvr_hip.so")
+
+VR_OK = 0
+VR_ERR_INVALID_ARG = -1
+VR_ERR_HIP = -2
+VR_ERR_NOT_READY = -3
+VR_ERR_UNSUPPORTED = -4
+VR_ERR_OOM = -5
+
+BASIC, LIGHT, VOLUME_MASK, THREE_FILES, MULTI_CTRT, TF_CALIB = range(6)
+VARIANT_NAMES = ["BASIC", "LIGHT", "VOLUME_MASK", "THREE_FILES", "MULTI_CTRT", "TF_CALIB"]
+TILE = 64
+
+# every symbol include/vr.h declares (tests check that the library exports each of them)
+ABI_SYMBOLS = [
+    "vr_create", "vr_resize", "vr_destroy", "vr_last_error", "vr_abi_version", "vr_volume_upload",
+    "vr_volume_upload_device", "vr_tf_upload", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
+    "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
+    "vr_last_timing", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_set_kernel_flavour",
+]
+
+
+class Uniforms(C.Structure):
+    """struct vr_uniforms (include/vr.h)."""
+    _fields_ = [
+        ("model", C.c_float * 16), ("view", C.c_float * 16), ("proj", C.c_float * 16),
+        ("view_inv", C.c_float * 16), ("proj_inv", C.c_float * 16),
+        ("camera_pos", C.c_float * 3),
+        ("fragment_mode", C.c_int32), ("steps_count", C.c_int32), ("step_size", C.c_float),
+        ("clip_x", C.c_float * 2), ("clip_y", C.c_float * 2), ("clip_z", C.c_float * 2),
+        ("toggles", C.c_int32 * 4),
+        ("light_pos", C.c_float * 4), ("light_ambient", C.c_float * 4), ("light_diffuse", C.c_float * 4),
+    ]
+
+
+class VrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vr error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libvr_hip.so; raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u32, u16 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint16
+    fp = C.POINTER(C.c_float)
+    lib.vr_create.argtypes = [C.POINTER(vp), u32, u32, i32]
+    lib.vr_resize.argtypes = [vp, u32, u32]
+    lib.vr_destroy.argtypes = [vp]
+    lib.vr_destroy.restype = None
+    lib.vr_last_error.argtypes = [vp]
+    lib.vr_last_error.restype = C.c_char_p
+    lib.vr_abi_version.argtypes = []
+    lib.vr_volume_upload.argtypes = [vp, i32, vp, u16, u16, u16]
+    lib.vr_volume_upload_device.argtypes = [vp, i32, vp, u16, u16, u16]
+    lib.vr_tf_upload.argtypes = [vp, i32, vp, vp, u32]
+    lib.vr_set_uniforms.argtypes = [vp, C.POINTER(Uniforms)]
+    lib.vr_render.argtypes = [vp, i32]
+    lib.vr_render_tiles.argtypes = [vp, i32, i32, i32]
+    lib.vr_tile_count.argtypes = [vp, i32, i32]
+    lib.vr_render_async.argtypes = [vp, i32, vp, vp]
+    lib.vr_render_tiles_async.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.vr_unpack_tiles_async.argtypes = [vp, vp, i32, vp, vp]
+    lib.vr_download.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
+    lib.vr_download_tiles.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+    lib.vr_last_timing.argtypes = [vp, fp, fp]
+    lib.vr_frame_device_ptr.argtypes = [vp]
+    lib.vr_frame_device_ptr.restype = vp
+    lib.vr_last_covered_pixels.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.vr_set_kernel_flavour.argtypes = [vp, i32]
+    _lib = lib
+    return lib
+
+
+def _f32(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+class Context:
+    """Thin RAII wrapper over vr_ctx."""
+
+    def __init__(self, width: int, height: int, device_id: int = 0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.vr_create(C.byref(self.h), width, height, device_id)
+        if rc != VR_OK:
+            raise VrError(rc, (self.lib.vr_last_error(None) or b"").decode())
+        self.width, self.height = width, height
+
+    def _chk(self, rc: int):
+        if rc < 0:
+            raise VrError(rc, (self.lib.vr_last_error(self.h) or b"").decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.lib.vr_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resize(self, w: int, h: int):
+        self._chk(self.lib.vr_resize(self.h, w, h))
+        self.width, self.height = w, h
+
+    def volume_upload(self, slot: int, vec4: np.ndarray):
+        """vec4: float32 array of shape (nz, ny, nx, 4)."""
+        v = _f32(vec4)
+        assert v.ndim == 4 and v.shape[3] == 4, v.shape
+        nz, ny, nx = v.shape[:3]
+        self._chk(self.lib.vr_volume_upload(self.h, slot, v.ctypes.data, nx, ny, nz))
+
+    def volume_upload_device(self, slot: int, dptr: int, nx: int, ny: int, nz: int):
+        self._chk(self.lib.vr_volume_upload_device(self.h, slot, dptr, nx, ny, nz))
+
+    def tf_upload(self, slot: int, opacity: np.ndarray, color_rgba: np.ndarray):
+        o, c = _f32(opacity), _f32(color_rgba)
+        assert c.size == 4 * o.size
+        self._chk(self.lib.vr_tf_upload(self.h, slot, o.ctypes.data, c.ctypes.data, o.size))
+
+    def set_uniforms(self, u: Uniforms):
+        self._chk(self.lib.vr_set_uniforms(self.h, C.byref(u)))
+
+    def render(self, variant: int):
+        self._chk(self.lib.vr_render(self.h, variant))
+
+    def render_tiles(self, variant: int, rank: int, world: int):
+        self._chk(self.lib.vr_render_tiles(self.h, variant, rank, world))
+
+    def tile_count(self, rank: int, world: int) -> int:
+        return self._chk(self.lib.vr_tile_count(self.h, rank, world))
+
+    def render_async(self, variant: int, d_frame: int = 0, stream: int = 0):
+        self._chk(self.lib.vr_render_async(self.h, variant, d_frame, stream))
+
+    def render_tiles_async(self, variant: int, rank: int, world: int, d_tiles: int, stream: int = 0):
+        self._chk(self.lib.vr_render_tiles_async(self.h, variant, rank, world, d_tiles, stream))
+
+    def unpack_tiles_async(self, d_gathered: int, world: int, d_frame: int = 0, stream: int = 0):
+        self._chk(self.lib.vr_unpack_tiles_async(self.h, d_gathered, world, d_frame, stream))
+
+    def download(self, present: bool = False):
+        """Returns (frag[H,W,4] float32, bgra8[H,W,4] uint8 or None, composited_samples)."""
+        frag = np.empty((self.height, self.width, 4), dtype=np.float32)
+        bgra = np.empty((self.height, self.width, 4), dtype=np.uint8) if present else None
+        n = C.c_uint64(0)
+        self._chk(self.lib.vr_download(self.h, frag.ctypes.data, bgra.ctypes.data if present else None, C.byref(n)))
+        return frag, bgra, int(n.value)
+
+    def samples(self) -> int:
+        n = C.c_uint64(0)
+        self._chk(self.lib.vr_download(self.h, None, None, C.byref(n)))
+        return int(n.value)
+
+    def download_tiles(self, n_tiles: int):
+        tiles = np.empty((n_tiles, TILE, TILE, 4), dtype=np.float32)
+        n = C.c_uint64(0)
+        self._chk(self.lib.vr_download_tiles(self.h, tiles.ctypes.data, C.byref(n)))
+        return tiles, int(n.value)
+
+    def last_timing(self):
+        k, t = C.c_float(0), C.c_float(0)
+        self._chk(self.lib.vr_last_timing(self.h, C.byref(k), C.byref(t)))
+        return float(k.value), float(t.value)
+
+    def covered_pixels(self) -> int:
+        n = C.c_uint64(0)
+        self._chk(self.lib.vr_last_covered_pixels(self.h, C.byref(n)))
+        return int(n.value)
+
+    def frame_device_ptr(self) -> int:
+        return int(self.lib.vr_frame_device_ptr(self.h) or 0)
+
+    def set_kernel_flavour(self, flavour: int):
+        self._chk(self.lib.vr_set_kernel_flavour(self.h, flavour))

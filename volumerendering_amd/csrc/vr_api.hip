@@ -1,0 +1,497 @@
+// vr_api.hip -- implementation of the C ABI declared in include/vr.h on top of the gfx950 kernels.
+// No CPU fallback exists behind this ABI (and nothing under oracle/ is referenced): without a usable HIP
+// device vr_create fails with VR_ERR_HIP.
+#include "../../include/vr.h"
+#include "vr_kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace vr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Timing {
+    hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
+    bool valid = false;
+};
+
+}  // namespace
+
+struct vr_ctx {
+    int device = 0;
+    uint32_t W = 0, H = 0;
+    hipStream_t stream = nullptr;
+    DevVolume vol[VR_MAX_VOLUMES] = {};
+    size_t vol_bytes[VR_MAX_VOLUMES] = {};
+    DevTF tf[VR_MAX_TFS] = {};
+    float* tf_opacity[VR_MAX_TFS] = {};
+    float4* tf_color[VR_MAX_TFS] = {};
+    vr_uniforms u = {};
+    bool have_uniforms = false;
+    float4* d_frame = nullptr;
+    float4* d_tiles = nullptr;
+    size_t tiles_cap = 0;       // in float4
+    int last_tiles = 0;         // tiles rendered by the last vr_render_tiles
+    uint32_t* d_present = nullptr;
+    unsigned long long* d_counters = nullptr;  // [2]
+    unsigned long long* h_counters = nullptr;  // pinned [2]
+    Timing tm;
+    int flavour = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(vr_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define VR_HIP(c, call)                                                                               \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return fail((c), e__ == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_HIP,                    \
+                        std::string(#call) + ": " + hipGetErrorString(e__));                          \
+    } while (0)
+
+int tiles_x_of(const vr_ctx* c) { return (int)((c->W + kTile - 1) / kTile); }
+int tiles_y_of(const vr_ctx* c) { return (int)((c->H + kTile - 1) / kTile); }
+
+int tile_count(const vr_ctx* c, int rank, int world)
+{
+    int total = tiles_x_of(c) * tiles_y_of(c);
+    if (rank >= total) return 0;
+    return (total - rank + world - 1) / world;
+}
+
+bool is_identity(const float* m)
+{
+    for (int i = 0; i < 16; ++i)
+        if (m[i] != ((i % 5 == 0) ? 1.0f : 0.0f)) return false;
+    return true;
+}
+
+// volumes / TF pairs each variant samples (vr.h slot tables)
+void variant_needs(int variant, int* nvol, int* ntf)
+{
+    switch (variant) {
+    case VR_VARIANT_BASIC:
+    case VR_VARIANT_LIGHT: *nvol = 1; *ntf = 1; break;
+    case VR_VARIANT_VOLUME_MASK: *nvol = 3; *ntf = 2; break;
+    case VR_VARIANT_THREE_FILES: *nvol = 2; *ntf = 2; break;  // the mask (slot 2) is bound but never sampled
+    case VR_VARIANT_MULTI_CTRT: *nvol = 2; *ntf = 2; break;
+    default: *nvol = 2; *ntf = 1; break;  // TF_CALIB
+    }
+}
+
+int alloc_frame(vr_ctx* c)
+{
+    VR_HIP(c, hipSetDevice(c->device));
+    if (c->d_frame) (void)hipFree(c->d_frame);
+    if (c->d_present) (void)hipFree(c->d_present);
+    c->d_frame = nullptr;
+    c->d_present = nullptr;
+    size_t n = (size_t)c->W * c->H;
+    VR_HIP(c, hipMalloc(&c->d_frame, n * sizeof(float4)));
+    VR_HIP(c, hipMalloc(&c->d_present, n * sizeof(uint32_t)));
+    VR_HIP(c, hipMemsetAsync(c->d_frame, 0, n * sizeof(float4), c->stream));
+    return VR_OK;
+}
+
+template <int V>
+void launch_variant(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
+{
+    if (off32)
+        hipLaunchKernelGGL((march_kernel<V, true>), grid, dim3(256), 0, s, P);
+    else
+        hipLaunchKernelGGL((march_kernel<V, false>), grid, dim3(256), 0, s, P);
+}
+
+// Enqueue one render on `s`.  out == nullptr -> ctx-owned buffer.
+int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, float4* out, hipStream_t s,
+                   bool record_events)
+{
+    if (variant < 0 || variant >= VR_VARIANT_COUNT) return fail(c, VR_ERR_INVALID_ARG, "vr_render: bad variant");
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, VR_ERR_INVALID_ARG, "vr_render: bad rank/world");
+    if (!c->have_uniforms) return fail(c, VR_ERR_NOT_READY, "vr_render: vr_set_uniforms has not been called");
+    int nvol, ntf;
+    variant_needs(variant, &nvol, &ntf);
+    bool off32 = true;
+    for (int i = 0; i < nvol; ++i) {
+        if (!c->vol[i].data) return fail(c, VR_ERR_NOT_READY, "vr_render: volume slot " + std::to_string(i) + " is empty");
+        if (c->vol_bytes[i] > 0xFFFFFFFFull) off32 = false;
+    }
+    for (int i = 0; i < ntf; ++i)
+        if (!c->tf[i].opacity) return fail(c, VR_ERR_NOT_READY, "vr_render: TF slot " + std::to_string(i) + " is empty");
+    if (c->u.steps_count < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: negative steps_count");
+    VR_HIP(c, hipSetDevice(c->device));
+
+    MarchParams P;
+    std::memset(&P, 0, sizeof P);
+    std::memcpy(P.proj_inv, c->u.proj_inv, sizeof P.proj_inv);
+    std::memcpy(P.view_inv, c->u.view_inv, sizeof P.view_inv);
+    P.W = (int)c->W;
+    P.H = (int)c->H;
+    P.fragment_mode = c->u.fragment_mode;
+    P.steps_count = c->u.steps_count;
+    P.step_size = c->u.step_size;
+    // IsInSampleCoords bounds, BasicVolumeApp.wgsl:73-74 (same f32 expressions as the shader)
+    P.bmin[0] = 0.0f + c->u.clip_x[0]; P.bmin[1] = 0.0f + c->u.clip_y[0]; P.bmin[2] = 0.0f + c->u.clip_z[0];
+    P.bmax[0] = 1.0f - c->u.clip_x[1]; P.bmax[1] = 1.0f - c->u.clip_y[1]; P.bmax[2] = 1.0f - c->u.clip_z[1];
+    P.toggle_varstep = c->u.toggles[0];
+    P.toggle_jitter = c->u.toggles[1];
+    for (int i = 0; i < 3; ++i) {
+        P.light_pos[i] = c->u.light_pos[i];
+        P.light_amb[i] = c->u.light_ambient[i];
+        P.light_dif[i] = c->u.light_diffuse[i];
+    }
+    for (int i = 0; i < VR_MAX_VOLUMES; ++i) P.vol[i] = c->vol[i];
+    for (int i = 0; i < VR_MAX_TFS; ++i) P.tf[i] = c->tf[i];
+    P.rank = rank;
+    P.world = world;
+    P.tiles_x = tiles_x_of(c);
+    P.tiles_y = tiles_y_of(c);
+    P.n_tiles = tile_count(c, rank, world);
+    P.packed = packed ? 1 : 0;
+    P.n_blocks = P.n_tiles * kBlocksPerTile;
+    P.counters = c->d_counters;
+
+    if (packed && !out) {
+        size_t need = (size_t)P.n_tiles * kTile * kTile;
+        if (need > c->tiles_cap) {
+            if (c->d_tiles) (void)hipFree(c->d_tiles);
+            c->d_tiles = nullptr;
+            c->tiles_cap = 0;
+            VR_HIP(c, hipMalloc(&c->d_tiles, (need ? need : 1) * sizeof(float4)));
+            c->tiles_cap = need;
+        }
+        out = c->d_tiles;
+    } else if (!out) {
+        out = c->d_frame;
+    }
+    P.out = out;
+    c->last_tiles = packed ? P.n_tiles : 0;
+
+    if (record_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
+    VR_HIP(c, hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), s));
+    if (P.n_blocks > 0) {
+        dim3 grid((unsigned)((P.n_blocks + 7) / 8 * 8));
+        if (record_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
+        switch (variant) {
+        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, grid, s, P); break;
+        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, grid, s, P); break;
+        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, grid, s, P); break;
+        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, grid, s, P); break;
+        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, grid, s, P); break;
+        default: launch_variant<V_TF_CALIB>(off32, grid, s, P); break;
+        }
+        VR_HIP(c, hipGetLastError());
+        if (record_events) VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
+    } else if (record_events) {
+        VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
+        VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
+    }
+    VR_HIP(c, hipMemcpyAsync(c->h_counters, c->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (record_events) {
+        VR_HIP(c, hipEventRecord(c->tm.ev_end, s));
+        c->tm.valid = true;
+    }
+    return VR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vr_abi_version(void) { return VR_ABI_VERSION; }
+
+const char* vr_last_error(const vr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
+{
+    if (!out) return fail(nullptr, VR_ERR_INVALID_ARG, "vr_create: out is NULL");
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768)
+        return fail(nullptr, VR_ERR_INVALID_ARG, "vr_create: bad viewport size");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, VR_ERR_HIP, std::string("vr_create: no HIP device available (") +
+                                             (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                                             "); this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, VR_ERR_INVALID_ARG, "vr_create: bad device_id");
+    vr_ctx* c = new (std::nothrow) vr_ctx();
+    if (!c) return fail(nullptr, VR_ERR_OOM, "vr_create: out of host memory");
+    c->device = device_id;
+    c->W = width;
+    c->H = height;
+    auto bail = [&](int code) {
+        g_create_error = c->err;
+        vr_destroy(c);
+        return code;
+    };
+    int rc;
+    auto hip_ok = [&](hipError_t he, const char* what) {
+        if (he == hipSuccess) return true;
+        c->err = std::string(what) + ": " + hipGetErrorString(he);
+        return false;
+    };
+    if (!hip_ok(hipSetDevice(device_id), "hipSetDevice")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipEventCreate(&c->tm.ev_begin), "hipEventCreate")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipEventCreate(&c->tm.ev_k0), "hipEventCreate")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipEventCreate(&c->tm.ev_k1), "hipEventCreate")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipEventCreate(&c->tm.ev_end), "hipEventCreate")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipMalloc(&c->d_counters, 2 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 2 * sizeof(unsigned long long), hipHostMallocDefault),
+                "hipHostMalloc"))
+        return bail(VR_ERR_HIP);
+    c->h_counters[0] = c->h_counters[1] = 0;
+    rc = alloc_frame(c);
+    if (rc != VR_OK) return bail(rc);
+    *out = c;
+    return VR_OK;
+}
+
+int vr_resize(vr_ctx* c, uint32_t width, uint32_t height)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768)
+        return fail(c, VR_ERR_INVALID_ARG, "vr_resize: bad viewport size");
+    (void)hipStreamSynchronize(c->stream);
+    c->W = width;
+    c->H = height;
+    return alloc_frame(c);
+}
+
+void vr_destroy(vr_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < VR_MAX_VOLUMES; ++i)
+        if (c->vol[i].data) (void)hipFree(const_cast<float4*>(c->vol[i].data));
+    for (int i = 0; i < VR_MAX_TFS; ++i) {
+        if (c->tf_opacity[i]) (void)hipFree(c->tf_opacity[i]);
+        if (c->tf_color[i]) (void)hipFree(c->tf_color[i]);
+    }
+    if (c->d_frame) (void)hipFree(c->d_frame);
+    if (c->d_tiles) (void)hipFree(c->d_tiles);
+    if (c->d_present) (void)hipFree(c->d_present);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
+    if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);
+    if (c->tm.ev_k1) (void)hipEventDestroy(c->tm.ev_k1);
+    if (c->tm.ev_end) (void)hipEventDestroy(c->tm.ev_end);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int volume_upload_common(vr_ctx* c, int slot, const void* src, bool src_is_device, uint16_t nx, uint16_t ny,
+                                uint16_t nz)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= VR_MAX_VOLUMES) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload: bad slot");
+    if (!src) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload: data is NULL");
+    if (nx == 0 || ny == 0 || nz == 0) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload: empty volume");
+    unsigned long long voxels = (unsigned long long)nx * ny * nz;
+    if (voxels > 0xFFFFFFFFull) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload: more than 2^32 voxels");
+    size_t bytes = (size_t)voxels * sizeof(float4);
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->vol[slot].data && c->vol_bytes[slot] != bytes) {
+        (void)hipFree(const_cast<float4*>(c->vol[slot].data));
+        c->vol[slot] = DevVolume{};
+        c->vol_bytes[slot] = 0;
+    }
+    float4* d = const_cast<float4*>(c->vol[slot].data);
+    if (!d) VR_HIP(c, hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpyAsync(d, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        if (!c->vol[slot].data) (void)hipFree(d);
+        return fail(c, VR_ERR_HIP, std::string("vr_volume_upload: copy failed: ") + hipGetErrorString(e));
+    }
+    c->vol[slot].data = d;
+    c->vol[slot].nx = nx;
+    c->vol[slot].ny = ny;
+    c->vol[slot].nz = nz;
+    c->vol_bytes[slot] = bytes;
+    return VR_OK;
+}
+
+int vr_volume_upload(vr_ctx* c, int slot, const float* vec4_voxels, uint16_t nx, uint16_t ny, uint16_t nz)
+{
+    return volume_upload_common(c, slot, vec4_voxels, false, nx, ny, nz);
+}
+
+int vr_volume_upload_device(vr_ctx* c, int slot, const void* d_vec4_voxels, uint16_t nx, uint16_t ny, uint16_t nz)
+{
+    return volume_upload_common(c, slot, d_vec4_voxels, true, nx, ny, nz);
+}
+
+int vr_tf_upload(vr_ctx* c, int slot, const float* opacity, const float* color_rgba, uint32_t R)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= VR_MAX_TFS) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: bad slot");
+    if (!opacity || !color_rgba) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: table is NULL");
+    if (R == 0 || R > (1u << 24)) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: bad resolution");
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->tf[slot].res != (int)R) {
+        if (c->tf_opacity[slot]) (void)hipFree(c->tf_opacity[slot]);
+        if (c->tf_color[slot]) (void)hipFree(c->tf_color[slot]);
+        c->tf_opacity[slot] = nullptr;
+        c->tf_color[slot] = nullptr;
+        c->tf[slot] = DevTF{};
+        VR_HIP(c, hipMalloc(&c->tf_opacity[slot], R * sizeof(float)));
+        VR_HIP(c, hipMalloc(&c->tf_color[slot], R * sizeof(float4)));
+    }
+    VR_HIP(c, hipMemcpyAsync(c->tf_opacity[slot], opacity, R * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->tf_color[slot], color_rgba, R * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    c->tf[slot].opacity = c->tf_opacity[slot];
+    c->tf[slot].color = c->tf_color[slot];
+    c->tf[slot].res = (int)R;
+    return VR_OK;
+}
+
+int vr_set_uniforms(vr_ctx* c, const vr_uniforms* u)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!u) return fail(c, VR_ERR_INVALID_ARG, "vr_set_uniforms: uniforms is NULL");
+    if (!is_identity(u->model))
+        return fail(c, VR_ERR_UNSUPPORTED,
+                    "vr_set_uniforms: model matrix must be the identity (the reference never uploads another one, "
+                    "App/src/Application.cpp:489-492)");
+    c->u = *u;
+    c->have_uniforms = true;
+    return VR_OK;
+}
+
+int vr_render(vr_ctx* c, int variant)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    int rc = enqueue_render(c, variant, 0, 1, false, nullptr, c->stream, true);
+    if (rc != VR_OK) return rc;
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    return VR_OK;
+}
+
+int vr_tile_count(const vr_ctx* c, int rank, int world)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world) return VR_ERR_INVALID_ARG;
+    return tile_count(c, rank, world);
+}
+
+int vr_render_tiles(vr_ctx* c, int variant, int rank, int world)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    int rc = enqueue_render(c, variant, rank, world, true, nullptr, c->stream, true);
+    if (rc != VR_OK) return rc;
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    return VR_OK;
+}
+
+int vr_render_async(vr_ctx* c, int variant, void* d_frame, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return enqueue_render(c, variant, 0, 1, false, (float4*)d_frame, s, true);
+}
+
+int vr_render_tiles_async(vr_ctx* c, int variant, int rank, int world, void* d_tiles, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return enqueue_render(c, variant, rank, world, true, (float4*)d_tiles, s, true);
+}
+
+int vr_unpack_tiles_async(vr_ctx* c, const void* d_gathered, int world, void* d_frame, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!d_gathered || world < 1) return fail(c, VR_ERR_INVALID_ARG, "vr_unpack_tiles_async: bad arguments");
+    VR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    float4* frame = d_frame ? (float4*)d_frame : c->d_frame;
+    int tpr = tile_count(c, 0, world);
+    dim3 block(64, 4), grid((c->W + 63) / 64, (c->H + 3) / 4);
+    hipLaunchKernelGGL(unpack_tiles_kernel, grid, block, 0, s, (const float4*)d_gathered, frame, (int)c->W, (int)c->H,
+                       tiles_x_of(c), world, tpr);
+    VR_HIP(c, hipGetLastError());
+    return VR_OK;
+}
+
+int vr_download(vr_ctx* c, float* frag_rgba, uint8_t* present_bgra8, uint64_t* composited_samples)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    size_t n = (size_t)c->W * c->H;
+    if (frag_rgba) VR_HIP(c, hipMemcpy(frag_rgba, c->d_frame, n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (present_bgra8) {
+        hipLaunchKernelGGL(present_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_frame,
+                           c->d_present, (int)n);
+        VR_HIP(c, hipGetLastError());
+        VR_HIP(c, hipStreamSynchronize(c->stream));
+        VR_HIP(c, hipMemcpy(present_bgra8, c->d_present, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    if (composited_samples) *composited_samples = c->h_counters[0];
+    return VR_OK;
+}
+
+int vr_download_tiles(vr_ctx* c, float* tiles_rgba, uint64_t* composited_samples)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    if (tiles_rgba && c->last_tiles > 0)
+        VR_HIP(c, hipMemcpy(tiles_rgba, c->d_tiles, (size_t)c->last_tiles * kTile * kTile * sizeof(float4),
+                            hipMemcpyDeviceToHost));
+    if (composited_samples) *composited_samples = c->h_counters[0];
+    return VR_OK;
+}
+
+int vr_last_timing(vr_ctx* c, float* kernel_ms, float* total_ms)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!c->tm.valid) return fail(c, VR_ERR_NOT_READY, "vr_last_timing: nothing rendered yet");
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipEventSynchronize(c->tm.ev_end));
+    float k = 0.0f, t = 0.0f;
+    VR_HIP(c, hipEventElapsedTime(&k, c->tm.ev_k0, c->tm.ev_k1));
+    VR_HIP(c, hipEventElapsedTime(&t, c->tm.ev_begin, c->tm.ev_end));
+    if (kernel_ms) *kernel_ms = k;
+    if (total_ms) *total_ms = t;
+    return VR_OK;
+}
+
+void* vr_frame_device_ptr(vr_ctx* c) { return c ? (void*)c->d_frame : nullptr; }
+
+int vr_last_covered_pixels(vr_ctx* c, uint64_t* covered)
+{
+    if (!c || !covered) return VR_ERR_INVALID_ARG;
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    *covered = c->h_counters[1];
+    return VR_OK;
+}
+
+int vr_set_kernel_flavour(vr_ctx* c, int flavour)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (flavour != 0) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    c->flavour = flavour;
+    return VR_OK;
+}
+
+}  // extern "C"

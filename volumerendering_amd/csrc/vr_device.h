@@ -1,0 +1,45 @@
+// vr_device.h -- device-side data structures shared by the kernels and the C-ABI implementation.
+// gfx950 (MI355X) only.  All arithmetic IEEE f32, compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vr {
+
+constexpr int kTile = 64;        // multi-GPU ownership granule (pixels)
+constexpr int kBlockEdge = 16;   // one 256-thread workgroup = 16x16 pixels = four 8x8 wave packets
+constexpr int kBlocksPerTile = (kTile / kBlockEdge) * (kTile / kBlockEdge);
+
+struct DevVolume {
+    const float4* data;  // reference layout: x fastest, (k*ny + j)*nx + i   (VolumeFile.cpp:306)
+    int nx, ny, nz;
+};
+
+struct DevTF {
+    const float* opacity;  // R32Float[res]     (OpacityTf.cpp:25-26)
+    const float4* color;   // RGBA32Float[res]  (ColorTf.cpp:23-24)
+    int res;
+};
+
+// Kernel argument block (passed by value, lives in SGPRs / kernarg segment).
+struct MarchParams {
+    float proj_inv[16];
+    float view_inv[16];
+    int W, H;
+    int fragment_mode;
+    int steps_count;
+    float step_size;
+    float bmin[3], bmax[3];  // IsInSampleCoords bounds: 0.0f + clip?.x, 1.0f - clip?.y
+    int toggle_varstep, toggle_jitter;
+    float light_pos[3], light_amb[3], light_dif[3];
+    DevVolume vol[3];
+    DevTF tf[2];
+    // work decomposition: the launch walks the 64x64 tiles t = rank + n*world, n = 0..n_tiles-1
+    int rank, world, tiles_x, tiles_y, n_tiles;
+    int packed;              // 0: write frame[y*W+x]; 1: write packed tiles
+    int n_blocks;            // logical blocks = n_tiles * kBlocksPerTile (grid is padded to a multiple of 8)
+    float4* out;
+    unsigned long long* counters;  // [0] composited samples, [1] covered pixels
+};
+
+}  // namespace vr

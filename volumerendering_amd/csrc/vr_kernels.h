@@ -1,0 +1,513 @@
+// vr_kernels.h -- hand-written HIP kernels for gfx950 (MI355X / CDNA4): the front-to-back compositing loop
+// of the reference's WGSL fragment shaders, one ray per lane, one 8x8 pixel packet per 64-wide wavefront.
+//
+// What each piece replaces (paths below the reference root):
+//   setup_ray()      rayCoords.wgsl:19-34 + vertex stage BasicVolumeApp.wgsl:44-57 + rasteriser, proxy box
+//                    Application.h:147-156, cull state Application.cpp:589-590,602-604
+//   tex3_*()         textureSample(texture_3d, samplerLin/NN, p): Sampler.cpp:9-24 (clamp-to-edge, single mip)
+//   tf_*()           textureSample(texture_1d, samplerLin, d)
+//   march_kernel<V>  fs_main of BasicVolumeApp.wgsl:113-188, BasicVolLightApp.wgsl:151-237,
+//                    VolumeMaskApp.wgsl:128-217, ThreeFilesApp.wgsl:170-272, MultiCTRTApp.wgsl:163-259,
+//                    TFCalibrationApp.wgsl:114-197
+//   present_kernel   output merge PipelineBuilder.cpp:142-147 over fullscreen.wgsl:33-41 white, BGRA8Unorm
+//
+// Arithmetic contract (DESIGN.md "Normative arithmetic"): IEEE f32, no FMA contraction (-ffp-contract=off),
+// correctly rounded divide and sqrt (hipcc default for HIP), dot = (x*x' + y*y') + z*z',
+// normalize(v) = v * (1/sqrt(dot(v,v))), max(x,0) = x > 0 ? x : 0, lerp(a,b,t) = a + (b-a)*t.
+// The loop is exact with respect to the WGSL: iterations that cannot blend (outside IsInSampleCoords, or after
+// the opacity cut-off) are skipped, never approximated; p and the world position still advance by repeated
+// addition, one step at a time, because start + i*step is not bit-equal to the reference's accumulation.
+#pragma once
+#include "vr_device.h"
+
+namespace vr {
+
+enum Variant : int { V_BASIC = 0, V_LIGHT = 1, V_VOLUME_MASK = 2, V_THREE_FILES = 3, V_MULTI_CTRT = 4, V_TF_CALIB = 5 };
+
+struct f3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ f3 normalize3(f3 a)
+{
+    float inv = 1.0f / length3(a);
+    return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
+__device__ __forceinline__ float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// column-major mat4 * (x,y,z,1), summed left to right
+__device__ __forceinline__ void mat4_mul_point(const float* m, float x, float y, float z, float w, float out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = ((m[0 + r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
+}
+
+// ------------------------------------------------------------------------------------------------ jitter
+// BasicVolumeApp.wgsl:107-110.  sin() is evaluated in f64 (quadrant reduction + Taylor) so that the value is
+// reproducible; once per pixel, only when toggles[1] == 1.
+__device__ inline double sin_d(double x)
+{
+    double n = rint(x * 0.63661977236758138);
+    double r = (x - n * 1.5707963267948966) - n * 6.123233995736766e-17;
+    long long q = ((long long)n) & 3;
+    double r2 = r * r;
+    double s = r2 * (1.0 / 6227020800.0);
+    s = r2 * (s + (-1.0 / 39916800.0));
+    s = r2 * (s + (1.0 / 362880.0));
+    s = r2 * (s + (-1.0 / 5040.0));
+    s = r2 * (s + (1.0 / 120.0));
+    s = r2 * (s + (-1.0 / 6.0));
+    s = r * (s + 1.0);
+    double c = r2 * (-1.0 / 87178291200.0);
+    c = r2 * (c + (1.0 / 479001600.0));
+    c = r2 * (c + (-1.0 / 3628800.0));
+    c = r2 * (c + (1.0 / 40320.0));
+    c = r2 * (c + (-1.0 / 720.0));
+    c = r2 * (c + (1.0 / 24.0));
+    c = r2 * (c + (-0.5));
+    c = c + 1.0;
+    return q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+}
+__device__ inline float jitter(float x, float y)
+{
+    float d = x * 12.9898f + y * 78.233f;
+    float s = (float)sin_d((double)d);
+    float v = s * 43758.5453f;
+    return v - floorf(v);
+}
+
+// ------------------------------------------------------------------------------------------------ sampling
+struct Cell {  // the 2x2x2 texel cell of one linear 3-D fetch
+    unsigned o000, o100, o010, o110, o001, o101, o011, o111;  // voxel indices
+    float fx, fy, fz;
+};
+
+__device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
+{
+    float x = p.x * (float)v.nx - 0.5f;
+    float y = p.y * (float)v.ny - 0.5f;
+    float z = p.z * (float)v.nz - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+    Cell c;
+    c.fx = x - x0;
+    c.fy = y - y0;
+    c.fz = z - z0;
+    int i0 = clampi((int)x0, 0, v.nx - 1), i1 = clampi((int)x0 + 1, 0, v.nx - 1);
+    int j0 = clampi((int)y0, 0, v.ny - 1), j1 = clampi((int)y0 + 1, 0, v.ny - 1);
+    int k0 = clampi((int)z0, 0, v.nz - 1), k1 = clampi((int)z0 + 1, 0, v.nz - 1);
+    unsigned r00 = ((unsigned)k0 * (unsigned)v.ny + (unsigned)j0) * (unsigned)v.nx;
+    unsigned r10 = ((unsigned)k0 * (unsigned)v.ny + (unsigned)j1) * (unsigned)v.nx;
+    unsigned r01 = ((unsigned)k1 * (unsigned)v.ny + (unsigned)j0) * (unsigned)v.nx;
+    unsigned r11 = ((unsigned)k1 * (unsigned)v.ny + (unsigned)j1) * (unsigned)v.nx;
+    c.o000 = r00 + (unsigned)i0; c.o100 = r00 + (unsigned)i1;
+    c.o010 = r10 + (unsigned)i0; c.o110 = r10 + (unsigned)i1;
+    c.o001 = r01 + (unsigned)i0; c.o101 = r01 + (unsigned)i1;
+    c.o011 = r11 + (unsigned)i0; c.o111 = r11 + (unsigned)i1;
+    return c;
+}
+
+// OFF32: every bound volume is < 4 GiB, so byte offsets fit 32 bits and the loads use SGPR-base + VGPR-offset
+// addressing; otherwise 64-bit addresses.
+template <bool OFF32>
+__device__ __forceinline__ float4 load_vec4(const float4* base, unsigned idx)
+{
+    if constexpr (OFF32) {
+        return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (idx << 4));
+    } else {
+        return base[(size_t)idx];
+    }
+}
+template <bool OFF32>
+__device__ __forceinline__ float load_a(const float4* base, unsigned idx)
+{
+    if constexpr (OFF32) {
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + ((idx << 4) + 12u));
+    } else {
+        return reinterpret_cast<const float*>(base + (size_t)idx)[3];
+    }
+}
+
+__device__ __forceinline__ float tri(float v000, float v100, float v010, float v110, float v001, float v101,
+                                     float v011, float v111, float fx, float fy, float fz)
+{
+    float c00 = lerpf(v000, v100, fx);
+    float c10 = lerpf(v010, v110, fx);
+    float c01 = lerpf(v001, v101, fx);
+    float c11 = lerpf(v011, v111, fx);
+    float c0 = lerpf(c00, c10, fy);
+    float c1 = lerpf(c01, c11, fy);
+    return lerpf(c0, c1, fz);
+}
+
+// textureSample(vol, samplerLin, p) -> all four channels
+template <bool OFF32>
+__device__ __forceinline__ float4 tex3_rgba(const DevVolume& v, f3 p)
+{
+    Cell c = make_cell(v, p);
+    float4 a = load_vec4<OFF32>(v.data, c.o000), b = load_vec4<OFF32>(v.data, c.o100);
+    float4 d = load_vec4<OFF32>(v.data, c.o010), e = load_vec4<OFF32>(v.data, c.o110);
+    float4 f = load_vec4<OFF32>(v.data, c.o001), g = load_vec4<OFF32>(v.data, c.o101);
+    float4 h = load_vec4<OFF32>(v.data, c.o011), i = load_vec4<OFF32>(v.data, c.o111);
+    float4 r;
+    r.x = tri(a.x, b.x, d.x, e.x, f.x, g.x, h.x, i.x, c.fx, c.fy, c.fz);
+    r.y = tri(a.y, b.y, d.y, e.y, f.y, g.y, h.y, i.y, c.fx, c.fy, c.fz);
+    r.z = tri(a.z, b.z, d.z, e.z, f.z, g.z, h.z, i.z, c.fx, c.fy, c.fz);
+    r.w = tri(a.w, b.w, d.w, e.w, f.w, g.w, h.w, i.w, c.fx, c.fy, c.fz);
+    return r;
+}
+
+// textureSample(vol, samplerLin, p).a  -- only the density plane of the vec4 voxels is touched
+template <bool OFF32>
+__device__ __forceinline__ float tex3_a(const DevVolume& v, f3 p)
+{
+    Cell c = make_cell(v, p);
+    float a = load_a<OFF32>(v.data, c.o000), b = load_a<OFF32>(v.data, c.o100);
+    float d = load_a<OFF32>(v.data, c.o010), e = load_a<OFF32>(v.data, c.o110);
+    float f = load_a<OFF32>(v.data, c.o001), g = load_a<OFF32>(v.data, c.o101);
+    float h = load_a<OFF32>(v.data, c.o011), i = load_a<OFF32>(v.data, c.o111);
+    return tri(a, b, d, e, f, g, h, i, c.fx, c.fy, c.fz);
+}
+
+// textureSample(vol, samplerNN, p)  (TFCalibrationApp.wgsl:172)
+template <bool OFF32>
+__device__ __forceinline__ float4 tex3_nearest(const DevVolume& v, f3 p)
+{
+    int i = clampi((int)floorf(p.x * (float)v.nx), 0, v.nx - 1);
+    int j = clampi((int)floorf(p.y * (float)v.ny), 0, v.ny - 1);
+    int k = clampi((int)floorf(p.z * (float)v.nz), 0, v.nz - 1);
+    unsigned idx = ((unsigned)k * (unsigned)v.ny + (unsigned)j) * (unsigned)v.nx + (unsigned)i;
+    return load_vec4<OFF32>(v.data, idx);
+}
+
+struct TfSample {
+    float opacity;
+    f3 rgb;
+};
+__device__ __forceinline__ TfSample tf_lookup(const DevTF& tf, float d)
+{
+    float x = d * (float)tf.res - 0.5f;
+    float x0 = floorf(x);
+    float f = x - x0;
+    int i0 = clampi((int)x0, 0, tf.res - 1), i1 = clampi((int)x0 + 1, 0, tf.res - 1);
+    float o0 = tf.opacity[i0], o1 = tf.opacity[i1];
+    float4 c0 = tf.color[i0], c1 = tf.color[i1];
+    TfSample s;
+    s.opacity = lerpf(o0, o1, f);
+    s.rgb = mk3(lerpf(c0.x, c1.x, f), lerpf(c0.y, c1.y, f), lerpf(c0.z, c1.z, f));
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ ray set-up
+struct Ray {
+    f3 start, end, world0;
+    bool hit;
+};
+
+__device__ __forceinline__ f3 unproject(const MarchParams& P, float nx, float ny, float nz)
+{
+    float v[4], w[4];
+    mat4_mul_point(P.proj_inv, nx, ny, nz, 1.0f, v);
+    float vx = v[0] / v[3], vy = v[1] / v[3], vz = v[2] / v[3];
+    mat4_mul_point(P.view_inv, vx, vy, vz, 1.0f, w);
+    return mk3(w[0], w[1], w[2]);
+}
+
+__device__ inline Ray setup_ray(const MarchParams& P, int px, int py)
+{
+    const float bmin[3] = {-0.5f, -0.5f, -0.25f};
+    const float bmax[3] = {0.5f, 0.5f, 0.25f};
+    Ray ray;
+    ray.hit = false;
+    float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    float ndcx = (2.0f * fx) / (float)P.W - 1.0f;
+    float ndcy = 1.0f - (2.0f * fy) / (float)P.H;
+    f3 O = unproject(P, ndcx, ndcy, 0.0f);
+    f3 F = unproject(P, ndcx, ndcy, 1.0f);
+    f3 D = mk3(F.x - O.x, F.y - O.y, F.z - O.z);
+    float seg = length3(D);
+    f3 dn = normalize3(D);
+    float o[3] = {O.x, O.y, O.z}, d[3] = {dn.x, dn.y, dn.z};
+    float t0 = -INFINITY, t1 = INFINITY;
+    int a0 = -1, a1 = -1;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (d[a] != 0.0f) {
+            float inv = 1.0f / d[a];
+            float ta = (bmin[a] - o[a]) * inv;
+            float tb = (bmax[a] - o[a]) * inv;
+            float tn = ta < tb ? ta : tb;
+            float tf = ta < tb ? tb : ta;
+            if (tn > t0) { t0 = tn; a0 = a; }
+            if (tf < t1) { t1 = tf; a1 = a; }
+        } else if (o[a] < bmin[a] || o[a] > bmax[a]) {
+            miss = true;
+        }
+    }
+    if (miss) return ray;
+    if (!(t0 < t1)) return ray;
+    if (!(t0 >= 0.0f && t0 <= seg)) return ray;
+    if (a0 < 0 || a1 < 0) return ray;
+    float P0[3], P1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        P0[a] = o[a] + d[a] * t0;
+        P1[a] = o[a] + d[a] * t1;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (a == a0) P0[a] = (d[a] > 0.0f) ? bmin[a] : bmax[a];
+        if (a == a1) P1[a] = (d[a] > 0.0f) ? bmax[a] : bmin[a];
+    }
+    ray.start = mk3(P0[0] + 0.5f, P0[1] + 0.5f, 0.5f - 2.0f * P0[2]);
+    ray.end = mk3(P1[0] + 0.5f, P1[1] + 0.5f, 0.5f - 2.0f * P1[2]);
+    ray.world0 = mk3(P0[0], P0[1], P0[2]);
+    ray.hit = true;
+    return ray;
+}
+
+// ------------------------------------------------------------------------------------------------ shading / blend
+__device__ __forceinline__ f3 shade(f3 N, f3 w, f3 lpos, f3 dif, f3 amb, float kD, float kA)
+{
+    f3 L = normalize3(mk3(lpos.x - w.x, lpos.y - w.y, lpos.z - w.z));
+    float m = max0(dot3(N, L));
+    return mk3((dif.x * m) * kD + amb.x * kA, (dif.y * m) * kD + amb.y * kA, (dif.z * m) * kD + amb.z * kA);
+}
+
+__device__ __forceinline__ void blend(f3 rgb, float a, float4& dst)  // FrontToBackBlend
+{
+    float sr = rgb.x * a, sg = rgb.y * a, sb = rgb.z * a;
+    float om = 1.0f - dst.w;
+    dst.x = om * sr + dst.x;
+    dst.y = om * sg + dst.y;
+    dst.z = om * sb + dst.z;
+    dst.w = om * a + dst.w;
+}
+
+template <int V>
+__device__ __forceinline__ bool can_blend(float a)  // the shader's opacity cut-off
+{
+    if constexpr (V == V_BASIC || V == V_MULTI_CTRT || V == V_TF_CALIB)
+        return a <= 0.95f;
+    else
+        return a < 1.0f;
+}
+
+// One loop iteration's body for a position that passed IsInSampleCoords and the cut-off.
+template <int V, bool OFF32>
+__device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst)
+{
+    if constexpr (V == V_BASIC) {
+        float density = tex3_a<OFF32>(P.vol[0], p);
+        TfSample t = tf_lookup(P.tf[0], density);
+        blend(t.rgb, t.opacity, dst);
+    } else if constexpr (V == V_LIGHT) {
+        float4 v = tex3_rgba<OFF32>(P.vol[0], p);
+        TfSample t = tf_lookup(P.tf[0], v.w);
+        f3 N = normalize3(mk3(v.x, v.y, v.z));
+        f3 s = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
+                     mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
+                     mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
+        blend(mk3(t.rgb.x * s.x, t.rgb.y * s.y, t.rgb.z * s.z), t.opacity, dst);
+    } else if constexpr (V == V_VOLUME_MASK) {
+        float4 mask = tex3_rgba<OFF32>(P.vol[0], p);
+        float rt = tex3_a<OFF32>(P.vol[1], p);
+        float4 ct = tex3_rgba<OFF32>(P.vol[2], p);
+        TfSample trt = tf_lookup(P.tf[1], rt);
+        TfSample tct = tf_lookup(P.tf[0], ct.w);
+        f3 N = normalize3(mk3(ct.x, ct.y, ct.z));
+        f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(0.96f, 0.76f, 0.67f), mk3(1.0f, 1.0f, 1.0f), 1.5f, 0.5f);
+        f3 col = mk3(tct.rgb.x * s.x, tct.rgb.y * s.y, tct.rgb.z * s.z);
+        float opacity = tct.opacity;
+        if (mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) {
+            opacity = trt.opacity;
+            col = trt.rgb;
+        }
+        blend(col, opacity, dst);
+    } else if constexpr (V == V_THREE_FILES) {
+        float ct = tex3_a<OFF32>(P.vol[0], p);
+        float rt = tex3_a<OFF32>(P.vol[1], p);
+        TfSample tct = tf_lookup(P.tf[0], ct);
+        TfSample trt = tf_lookup(P.tf[1], rt);
+        float om = 1.0f - trt.opacity;
+        f3 col = mk3(tct.rgb.x * om + trt.rgb.x * trt.opacity, tct.rgb.y * om + trt.rgb.y * trt.opacity,
+                     tct.rgb.z * om + trt.rgb.z * trt.opacity);
+        blend(col, tct.opacity, dst);
+    } else if constexpr (V == V_MULTI_CTRT) {
+        float4 ct = tex3_rgba<OFF32>(P.vol[0], p);
+        float rt = tex3_a<OFF32>(P.vol[1], p);
+        TfSample tct = tf_lookup(P.tf[0], ct.w);
+        TfSample trt = tf_lookup(P.tf[1], rt);
+        float om = 1.0f - trt.opacity;
+        f3 col = mk3(tct.rgb.x * om + trt.rgb.x * trt.opacity, tct.rgb.y * om + trt.rgb.y * trt.opacity,
+                     tct.rgb.z * om + trt.rgb.z * trt.opacity);
+        f3 g = mk3(ct.x, ct.y, ct.z);
+        f3 N = normalize3(g);
+        f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
+                     mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 3.5f, 0.5f);
+        col = mk3(col.x * s.x, col.y * s.y, col.z * s.z);
+        float opacity = tct.opacity * length3(g);
+        blend(col, opacity, dst);
+    } else {  // V_TF_CALIB
+        float density = tex3_a<OFF32>(P.vol[0], p);
+        float4 mask = tex3_nearest<OFF32>(P.vol[1], p);
+        TfSample t = tf_lookup(P.tf[0], density);
+        if (mask.x > 0.0f) {
+            t.rgb = mk3(1.0f, 1.0f, 0.0f);
+            t.opacity = 0.1f;
+        }
+        blend(t.rgb, t.opacity, dst);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ work mapping
+// The launch walks 64x64 screen tiles (the multi-GPU ownership granule); a workgroup is a 16x16 pixel block
+// of a tile, a wavefront an 8x8 packet of it.  blockIdx is de-interleaved over the 8 XCDs so that each XCD's
+// L2 sees a contiguous run of neighbouring blocks (blocks b and b+8 share an XCD; performance only).
+struct PixelSlot {
+    int px, py;      // screen pixel
+    int out_index;   // where dst goes (frame index, or packed-tile index)
+    bool active;     // inside the viewport and inside the launch
+};
+
+__device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
+{
+    PixelSlot s;
+    const int nb_pad = gridDim.x;  // multiple of 8
+    const int per_xcd = nb_pad >> 3;
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int n = lb / kBlocksPerTile;
+    const int sub = lb - n * kBlocksPerTile;
+    const int t = P.rank + n * P.world;
+    const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = ((wave & 1) << 3) + (lane & 7);
+    const int ly = ((wave >> 1) << 3) + (lane >> 3);
+    const int tpx = ((sub & 3) << 4) + lx, tpy = ((sub >> 2) << 4) + ly;  // pixel inside the tile
+    s.px = tx * kTile + tpx;
+    s.py = ty * kTile + tpy;
+    s.active = (lb < P.n_blocks) && (s.px < P.W) && (s.py < P.H);
+    s.out_index = P.packed ? (n * (kTile * kTile) + tpy * kTile + tpx) : (s.py * P.W + s.px);
+    return s;
+}
+
+template <int V, bool OFF32>
+__global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
+{
+    PixelSlot slot = map_pixel(P);
+    float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    unsigned blends = 0, covered = 0;
+
+    if (slot.active) {
+        Ray ray = setup_ray(P, slot.px, slot.py);
+        if (ray.hit) {
+            covered = 1;
+            f3 diff = mk3(ray.end.x - ray.start.x, ray.end.y - ray.start.y, ray.end.z - ray.start.z);
+            f3 dir = normalize3(diff);
+            float ray_len = length3(diff);
+            if (P.fragment_mode == 1) {
+                dst = make_float4(fabsf(dir.x), fabsf(dir.y), fabsf(dir.z), 1.0f);
+            } else if (P.fragment_mode == 2) {
+                dst = make_float4(ray.start.x, ray.start.y, ray.start.z, 1.0f);
+            } else if (P.fragment_mode == 3) {
+                dst = make_float4(ray.end.x, ray.end.y, ray.end.z, 1.0f);
+            } else if (P.fragment_mode == 4) {
+                dst = make_float4(0.5f * (ray.world0.x / 1.0f) + 0.5f, -0.5f * (ray.world0.y / 1.0f) + 0.5f, 0.0f, 1.0f);
+            } else {
+                float step_size = P.step_size;
+                f3 wstep = mk3(0.0f, 0.0f, 0.0f);
+                if constexpr (V == V_LIGHT) {  // CalculateWorldStep before the override
+                    wstep = mk3(dir.x * (step_size * 1.0f), dir.y * (step_size * 1.0f), dir.z * (step_size * 0.5f));
+                    wstep.z = wstep.z * (-1.0f);
+                }
+                if (P.toggle_varstep == 1) step_size = ray_len / (float)P.steps_count;
+                f3 p = ray.start;
+                if (P.toggle_jitter == 1) {
+                    float j = jitter((float)slot.px + 0.5f, (float)slot.py + 0.5f);
+                    p = mk3(p.x + (dir.x * step_size) * j, p.y + (dir.y * step_size) * j, p.z + (dir.z * step_size) * j);
+                }
+                f3 step = mk3(dir.x * step_size, dir.y * step_size, dir.z * step_size);
+                if constexpr (V == V_MULTI_CTRT) {  // CalculateWorldStep after the override
+                    wstep = mk3(dir.x * (step_size * 1.0f), dir.y * (step_size * 1.0f), dir.z * (step_size * 0.7f));
+                    wstep.z = wstep.z * (-1.0f);
+                }
+                if constexpr (V == V_VOLUME_MASK || V == V_THREE_FILES) wstep = step;
+                f3 w = ray.world0;
+                const float bx0 = P.bmin[0], by0 = P.bmin[1], bz0 = P.bmin[2];
+                const float bx1 = P.bmax[0], by1 = P.bmax[1], bz1 = P.bmax[2];
+                for (int i = 0; i < P.steps_count; ++i) {
+                    bool inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
+                    if (inb) {
+                        sample_and_blend<V, OFF32>(P, p, w, dst);
+                        ++blends;
+                        if (!can_blend<V>(dst.w)) break;  // cut-off reached: no later iteration can blend
+                    } else {
+                        // p moves monotonically per component: once past the far bound it never returns
+                        bool gone = (step.x >= 0.0f && p.x > bx1) || (step.x <= 0.0f && p.x < bx0) ||
+                                    (step.y >= 0.0f && p.y > by1) || (step.y <= 0.0f && p.y < by0) ||
+                                    (step.z >= 0.0f && p.z > bz1) || (step.z <= 0.0f && p.z < bz0);
+                        if (gone) break;
+                    }
+                    p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                    if constexpr (V != V_BASIC && V != V_TF_CALIB) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                }
+            }
+        }
+    }
+
+    // packed-tile launches write every slot of an owned tile (pixels outside the viewport = 0)
+    const int nb_pad = gridDim.x;
+    const int lb = (blockIdx.x & 7) * (nb_pad >> 3) + (blockIdx.x >> 3);
+    if (slot.active || (P.packed && lb < P.n_blocks)) P.out[slot.out_index] = dst;
+
+    // counters: wave reduction, one atomic pair per wave
+    unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) packed_cnt += __shfl_down(packed_cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && packed_cnt != 0) {
+        atomicAdd(&P.counters[0], packed_cnt & ((1ull << 40) - 1));
+        atomicAdd(&P.counters[1], packed_cnt >> 40);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ aux kernels
+__device__ __forceinline__ unsigned unorm8(float v)
+{
+    if (!(v > 0.0f)) v = 0.0f;
+    if (v > 1.0f) v = 1.0f;
+    return (unsigned)floorf(v * 255.0f + 0.5f);
+}
+
+// Output merge over the white background, BGRA8Unorm (PipelineBuilder.cpp:142-147, fullscreen.wgsl:33-41).
+__global__ void present_kernel(const float4* __restrict__ frag, uint32_t* __restrict__ bgra, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = frag[i];
+    float a = s.w;
+    float r = s.x * a + 1.0f * (1.0f - a);
+    float g = s.y * a + 1.0f * (1.0f - a);
+    float b = s.z * a + 1.0f * (1.0f - a);
+    float oa = s.w * a + 1.0f * (1.0f - a);
+    bgra[i] = unorm8(b) | (unorm8(g) << 8) | (unorm8(r) << 16) | (unorm8(oa) << 24);
+}
+
+// Root side of the image-tile gather: gathered[r][n][64*64] -> frame[y*W+x]
+__global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4* __restrict__ frame, int W, int H,
+                                    int tiles_x, int world, int tiles_per_rank_max)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    int t = (y / kTile) * tiles_x + (x / kTile);
+    int r = t % world, n = t / world;
+    size_t src = ((size_t)r * tiles_per_rank_max + n) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile);
+    frame[(size_t)y * W + x] = gathered[src];
+}
+
+}  // namespace vr
