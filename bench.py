@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gsamples/s + fps of the volume ray-march compositing loop (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W           (N = 1 here; N > 1 under torch.distributed.run)
+
+A "step" is one rendered frame of the hot path on synthetic input that is already resident in HBM.  At N = 1 the
+workload is BASELINE.json configs[2] -- the one the metric is quoted on: ct-phantom-512 (512^3 RGBA32F voxels,
+2 GiB), 1920x1080, BasicVolLightApp shader (TF lookup + interpolated central-difference gradient + Blinn-Phong
+shade + opacity cut-off), default ramp TFs (R = 4096), 1/512 x 886 steps, camera distance 1.2 / yaw .6 / pitch .35.
+At N > 1 the same frame is image-tile partitioned (64x64 tiles, tile t owned by rank t mod N), each rank renders
+its tiles from its own replica of the volume and an RCCL gather over xGMI assembles the frame on rank 0
+("strong" scaling: total work fixed).  value = composited samples of the whole frame / wall time per frame.
+
+Rank 0 prints ONE JSON line; it also carries `roofline` (effective-gather bytes of the march kernel against the
+8 TB/s HBM peak, kernel time from HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on the
+host cores of this box on a bounded pixel sample of the same frame; N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+# per-composited-sample algorithmic bytes: the f32 footprint of one trilinear cell
+BYTES_PER_SAMPLE = {"BASIC": 32, "LIGHT": 128, "VOLUME_MASK": 288, "THREE_FILES": 64, "MULTI_CTRT": 160, "TF_CALIB": 48}
+
+WORKLOADS = {
+    # name: (volume N, W, H, variant)
+    "C1": (64, 256, 256, "BASIC"),
+    "C2": (256, 1024, 1024, "BASIC"),
+    "C3": (512, 1920, 1080, "LIGHT"),
+    "C4": (512, 1920, 1080, "VOLUME_MASK"),
+    "C5": (1024, 3840, 2160, "LIGHT"),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_scene(app, host, synth, capi, workload, tf_kind):
+    """Generates the synthetic inputs, runs the reference's data-prep order through the C++ host classes and
+    starts the scene on `app` (uploads happen here, outside any timed region)."""
+    n, W, H, vname = WORKLOADS[workload]
+    variant = capi.VARIANT_NAMES.index(vname)
+    t0 = time.time()
+    raw = synth.sphere_raw_fast(n) if workload == "C1" else synth.ct_phantom_raw_fast(n)
+    ct = host.VolumeFile.from_raw(raw)
+    del raw
+    vols = [ct]
+    if vname == "VOLUME_MASK":
+        mask = host.VolumeFile.from_vec4(synth.mask_vec4_fast(n), 1)
+        dose = host.VolumeFile.from_raw(synth.dose_raw())
+        vols = [mask, dose, ct]
+    app.OnStart(variant, vols)  # NormalizeData / PreComputeGradient in the scene's own order + uploads
+    if tf_kind == "thin":  # control points (0,0),(R-1,0.002): no ray terminates
+        for which in range(2 if vname == "VOLUME_MASK" else 1):
+            otf = app.scene_opacity_tf(which)
+            otf.SetControlPoint(1, otf.GetTextureResolution() - 1, 0.002)
+    cam = app.camera()
+    cam.SetOrbit(0.35, 0.6, 1.2)
+    app.OnUpdate()
+    log(f"[bench] scene {workload} ({vname}, {n}^3, {W}x{H}, tf={tf_kind}) ready in {time.time() - t0:.1f}s")
+    return variant, vols
+
+
+def cpu_baseline(app, capi, variant, vols, W, H, budget_s=15.0):
+    """Times the CPU oracle (a port: plain-C restatement of the WGSL) on a bounded, regular sub-grid of the SAME
+    frame, on all host cores.  Reported baseline only; never part of the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import host_ref as hr
+    import oracle_binding as ob
+
+    cores = os.cpu_count() or 1
+    u = app.uniforms()
+    uo = hr.Uniforms.from_buffer_copy(bytes(u))
+    volumes = [v.data() for v in vols]
+    tfs = []
+    for which in range(2 if len(vols) == 3 else 1):
+        tfs.append((app.scene_opacity_tf(which).table(), app.scene_color_tf(which).table()))
+    # calibrate the stride on a coarse grid, then size the sample for ~budget_s of wall time
+    stride = 32
+    value, sample = None, ""
+    for _ in range(3):
+        ys, xs = np.meshgrid(np.arange(stride // 2, H, stride), np.arange(stride // 2, W, stride), indexing="ij")
+        pxy = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.int32)
+        t0 = time.perf_counter()
+        _, n = ob.render_pixels(variant, uo, volumes, tfs, W, H, pxy, nthreads=cores)
+        dt = time.perf_counter() - t0
+        value = n / dt / 1e9 if dt > 0 else 0.0
+        sample = (f"every {stride}th pixel in x and y of the {W}x{H} frame ({pxy.shape[0]} rays, {n} composited "
+                  f"samples, {dt:.2f} s)")
+        if dt >= budget_s / 4 or stride <= 2:
+            break
+        stride = max(2, int(stride / math.sqrt(min(16.0, (budget_s / 2) / max(dt, 1e-3)))))
+    return {"value": round(value, 6), "unit": "Gsamples/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--tf", default="default", choices=["default", "thin"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flavour", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    from volumerendering_amd import capi, host, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n, W, H, vname = WORKLOADS[args.workload]
+    app = host.Application(W, H, local_rank)
+    variant, vols = build_scene(app, host, synth, capi, args.workload, args.tf)
+    ctx = app.context()
+    if args.flavour:
+        ctx.set_kernel_flavour(args.flavour)
+    steps_count, step_size = app.stepping()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    tpr_max = ctx.tile_count(0, world)
+    tile_floats = capi.TILE * capi.TILE * 4
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    if world > 1:
+        my_tiles = torch.zeros((tpr_max * tile_floats,), dtype=torch.float32, device="cuda")
+        gathered = torch.zeros((world, tpr_max * tile_floats), dtype=torch.float32, device="cuda") if rank == 0 else None
+        gather_list = [gathered[r] for r in range(world)] if rank == 0 else None
+
+    def one_frame():
+        if world == 1:
+            ctx.render_async(variant, frame.data_ptr(), stream)
+        else:
+            ctx.render_tiles_async(variant, rank, world, my_tiles.data_ptr(), stream)
+            dist.gather(my_tiles, gather_list, dst=0)  # RCCL over xGMI: every peer sends straight to the root
+            if rank == 0:
+                ctx.unpack_tiles_async(gathered.data_ptr(), world, frame.data_ptr(), stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_frame()
+    sync_all()
+    ctx.reset_kernel_times()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_frame()
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    my_samples = ctx.samples()       # composited samples of this rank's share of the last frame
+    my_covered = ctx.covered_pixels()
+    ktimes = ctx.kernel_times(min(args.steps, 256))
+    kernel_ms = float(np.mean(ktimes)) if len(ktimes) else float("nan")
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        s = torch.tensor([my_samples, my_covered], dtype=torch.int64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        total_samples, covered = int(s[0].item()), int(s[1].item())
+    else:
+        total_samples, covered = my_samples, my_covered
+
+    ms_per_step = dt / args.steps * 1e3
+    value = total_samples / (dt / args.steps) / 1e9
+    bs = BYTES_PER_SAMPLE[vname]
+    # dominant kernel = march_kernel; algorithmic bytes per launch = this rank's samples * B_s + the 16 B/pixel
+    # frame write of the pixels it owns (ray set-up is fused into the kernel: no ray-end image is read)
+    owned_px = W * H if world == 1 else ctx.tile_count(rank, world) * capi.TILE * capi.TILE
+    alg_bytes = my_samples * bs + 16 * owned_px
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms and kernel_ms > 0 else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("tf") == args.tf and tj.get("n_gpus") == world:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "Gsamples/s", "value": round(value, 4), "unit": "Gsamples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "fps": round(1e3 / ms_per_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, "
+                        f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
+            "partition": "single GPU" if world == 1 else f"64x64 image tiles interleaved over {world} GPUs + RCCL gather",
+            "composited_samples_per_frame": total_samples, "covered_pixels": covered,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+            "kernel": "march_kernel", "kernel_ms": round(kernel_ms, 4), "bytes_per_sample": bs,
+            "algorithmic_bytes_per_launch": alg_bytes,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(app, capi, variant, vols, W, H)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    app.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,6 +128,11 @@ int vr_volume_upload_device(vr_ctx* ctx, int slot, const void* d_vec4_voxels, ui
  * (R32Float 1-D), color_rgba: 4R floats (RGBA32Float 1-D).                                       */
 int vr_tf_upload(vr_ctx* ctx, int slot, const float* opacity, const float* color_rgba, uint32_t resolution);
 
+/* The two textures of a pair are separate objects in the reference and may differ in resolution (OpacityTF::Load
+ * re-resolves only its own, OpacityTf.cpp:298): upload one table of a slot without touching the other.       */
+int vr_tf_upload_opacity(vr_ctx* ctx, int slot, const float* opacity, uint32_t resolution);
+int vr_tf_upload_color(vr_ctx* ctx, int slot, const float* color_rgba, uint32_t resolution);
+
 /* Replaces: the 12 wgpuQueueWriteBuffer calls of Application::OnUpdate (Application.cpp:96-119)
  * plus the scene's Light uniform (BasicVolLightApp.cpp:42).  Returns VR_ERR_UNSUPPORTED when
  * `model` is not the identity (the reference never uploads anything else).                       */
@@ -176,6 +181,12 @@ int vr_download_tiles(vr_ctx* ctx, float* tiles_rgba, uint64_t* composited_sampl
  * march, counters), in milliseconds; valid after a synchronous render or after the caller
  * synchronised the stream.  Replaces the FPS / frame-time read-out (Application.cpp:339-370).    */
 int vr_last_timing(vr_ctx* ctx, float* kernel_ms, float* total_ms);
+
+/* HIP-event durations (ms) of the march kernel for the most recent render calls, oldest first, recorded on
+ * the stream each render was enqueued on; at most `capacity` (<= 256) values are written, the number written is
+ * returned (negative = error).  Synchronises on the newest event.  vr_reset_kernel_times() empties the ring.  */
+int vr_kernel_times(vr_ctx* ctx, float* out_ms, int capacity);
+int vr_reset_kernel_times(vr_ctx* ctx);
 
 /* Device pointer of the ctx-owned frame buffer (W*H*4 floats) written by vr_render. */
 void* vr_frame_device_ptr(vr_ctx* ctx);

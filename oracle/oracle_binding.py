@@ -22,7 +22,7 @@ class Volume(C.Structure):
 
 
 class TF(C.Structure):
-    _fields_ = [("opacity", C.c_void_p), ("color_rgba", C.c_void_p), ("res", C.c_int32)]
+    _fields_ = [("opacity", C.c_void_p), ("color_rgba", C.c_void_p), ("res", C.c_int32), ("res_color", C.c_int32)]
 
 
 _lib = None
@@ -79,7 +79,7 @@ def _pack(volumes, tfs):
         o = np.ascontiguousarray(t[0], dtype=np.float32)
         c = np.ascontiguousarray(t[1], dtype=np.float32)
         keep += [o, c]
-        tf_arr[i] = TF(o.ctypes.data, c.ctypes.data, o.size)
+        tf_arr[i] = TF(o.ctypes.data, c.ctypes.data, o.size, c.size // 4)
     return vols, tf_arr, keep
 
 

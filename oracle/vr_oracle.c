@@ -145,7 +145,7 @@ static float tf_opacity(const vro_tf* tf, float d) /* textureSample(tfOpacity, s
 static void tf_color(const vro_tf* tf, float d, float rgb[3]) /* textureSample(tfColor, samplerLin, d).rgb */
 {
     int i0, i1; float f;
-    tf_coords(tf->res, d, &i0, &i1, &f);
+    tf_coords(tf->res_color, d, &i0, &i1, &f);
     for (int c = 0; c < 3; ++c) rgb[c] = lerpf(tf->color_rgba[4 * i0 + c], tf->color_rgba[4 * i1 + c], f);
 }
 

@@ -30,7 +30,7 @@ typedef struct vro_uniforms {
 } vro_uniforms;
 
 typedef struct vro_volume { const float* vec4; int32_t nx, ny, nz; } vro_volume; /* x fastest, 4 floats/voxel */
-typedef struct vro_tf { const float* opacity; const float* color_rgba; int32_t res; } vro_tf;
+typedef struct vro_tf { const float* opacity; const float* color_rgba; int32_t res; int32_t res_color; } vro_tf; /* res = opacity table */
 
 enum { VRO_BASIC = 0, VRO_LIGHT = 1, VRO_VOLUME_MASK = 2, VRO_THREE_FILES = 3, VRO_MULTI_CTRT = 4, VRO_TF_CALIB = 5 };
 

@@ -1,0 +1,233 @@
+"""The C++ host surface (libvr_host.so: VolumeFile / OpacityTF / ColorTF / Camera, mirroring the reference's
+classes) against the oracle's restatements: bit-exact for the f32 data-prep and table arithmetic, 1e-6 for the
+camera (libm cos/sin/tan versus numpy's)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import host_ref as hr
+import oracle_binding as ob
+from volumerendering_amd import host
+
+f32 = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("shape", [(12, 12, 12), (5, 9, 14), (1, 1, 1), (2, 7, 1)])
+def test_normalize_then_gradient_matches_reference_order(shape):
+    rng = np.random.default_rng(7)
+    raw = rng.integers(0, 4096, size=shape, dtype=np.uint16)
+    raw.flat[0] = 4095
+    vf = host.VolumeFile.from_raw(raw)
+    assert vf.GetSize() == (shape[2], shape[1], shape[0])
+    assert vf.GetMaxNumber() == 4095
+    ref = hr.raw_to_vec4(raw)
+    assert np.array_equal(vf.data(), ref)
+    vf.NormalizeData()
+    ref = ob.normalize_data(ref)
+    assert np.array_equal(bits(vf.data()), bits(ref))
+    assert vf.GetDataRange() == 4095
+    vf.PreComputeGradient()
+    ref = ob.precompute_gradient(ref)
+    assert np.array_equal(bits(vf.data()), bits(ref))
+    before = vf.data().copy()
+    vf.AverageGradient(5)  # the reference's AverageGradient computes and discards: nothing changes
+    vf.PreComputeGradient()  # second call is skipped ("already computed")
+    assert np.array_equal(bits(vf.data()), bits(before))
+
+
+def test_gradient_normalised_to_zero_one_before_normalisation():
+    """VolumeMaskApp / MultiCTRTApp order: PreComputeGradient(true) on raw values, then NormalizeData."""
+    raw = hr.ct_phantom_raw(20)
+    vf = host.VolumeFile.from_raw(raw)
+    vf.PreComputeGradient(True)
+    vf.NormalizeData()
+    ref = ob.normalize_data(ob.precompute_gradient(hr.raw_to_vec4(raw), True), int(raw.max()))
+    assert np.array_equal(bits(vf.data()), bits(ref))
+    g = vf.data()[..., :3]
+    assert abs(float(np.sqrt((g.astype(np.float64) ** 2).sum(-1)).max()) - 1.0) < 1e-6
+
+
+def test_gradient_is_thread_count_invariant():
+    raw = hr.ct_phantom_raw(24)
+    outs = []
+    for n in (1, 3, 8):
+        host.load().vrh_set_worker_threads(n)
+        vf = host.VolumeFile.from_raw(raw)
+        vf.NormalizeData()
+        vf.PreComputeGradient(True)
+        outs.append(vf.data().copy())
+    host.load().vrh_set_worker_threads(0)
+    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+
+
+def test_uint32_dose_path_and_indexing():
+    raw = hr.dose_raw(16, 12, 8)
+    vf = host.VolumeFile.from_raw(raw)
+    assert vf.GetSize() == (16, 12, 8)
+    assert vf.GetIndexFrom3D(3, 2, 1) == 1 * 12 * 16 + 2 * 16 + 3
+    assert vf.GetIndexFrom3D(-1, 0, 0) == -1 and vf.GetIndexFrom3D(16, 0, 0) == -1 and vf.GetIndexFrom3D(0, 0, 8) == -1
+    assert vf.GetVoxelData(0, 12, 0) == (0.0, 0.0, 0.0, 0.0)
+    assert vf.GetVoxelData(3, 2, 1)[3] == float(raw[1, 2, 3])
+    assert vf.GetBBOXSize() == (1.0, 0.75, 0.5)
+    vf.NormalizeData()
+    assert float(vf.data()[..., 3].max()) == 1.0
+
+
+@pytest.mark.parametrize("res", [2, 256, 1024, 4096])
+def test_default_tf_tables(res):
+    o, c = host.OpacityTF(res), host.ColorTF(res)
+    assert o.GetTextureResolution() == res
+    assert np.array_equal(bits(o.table()), bits(hr.default_opacity_tf(res)))
+    assert np.array_equal(bits(c.table()), bits(hr.default_color_tf(res)))
+    assert o.GetControlPoints() == [(0.0, 0.0), (res - 1.0, 1.0)]
+
+
+def test_resolution_is_clamped_like_max_texture_dimension():
+    assert host.OpacityTF(0).GetTextureResolution() == 8192
+    assert host.OpacityTF(100000).GetTextureResolution() == 8192
+    assert host.ColorTF(-3).GetTextureResolution() == 8192
+
+
+def test_control_point_edit_relerps_integer_spans():
+    R = 64
+    o = host.OpacityTF(R)
+    assert o.AddControlPoint(20.4, 0.8) == 1       # x rounds to 20
+    assert o.AddControlPoint(20.0, 0.1) == -1      # already exists
+    assert o.AddControlPoint(40.0, 0.2) == 2
+    t = o.table()
+    # UpdateYAxis(1) at insertion: [0,20] from table[0] to 0.8, [20,63] from 0.8 to table[63]
+    exp = hr.default_opacity_tf(R).copy()
+    exp[0:21] = ob.lerp_float(0, 20, exp[0], f32(0.8))
+    exp[20:64] = ob.lerp_float(20, 63, f32(0.8), exp[63])
+    # then cp at 40: [20,40] from table[20] to 0.2, [40,63] from 0.2 to table[63]
+    exp[20:41] = ob.lerp_float(20, 40, exp[20], f32(0.2))
+    exp[40:64] = ob.lerp_float(40, 63, f32(0.2), exp[63])
+    assert np.array_equal(bits(t), bits(exp))
+    o.SetControlPoint(1, 25.0, 0.5)  # drag
+    assert o.GetControlPoints()[1] == (25.0, 0.5)
+    o.ResetTF()
+    assert np.array_equal(bits(o.table()), bits(hr.default_opacity_tf(R)))
+
+
+def test_color_control_points():
+    R = 32
+    c = host.ColorTF(R)
+    assert c.AddColorControlPoint(10, (1.0, 0.0, 0.0, 1.0)) == 1
+    t = c.table()
+    exp = hr.default_color_tf(R).copy()
+    exp[0:11] = ob.lerp_vec4(0, 10, exp[0], [1, 0, 0, 1])
+    exp[10:32] = ob.lerp_vec4(10, 31, [1, 0, 0, 1], exp[31])
+    assert np.array_equal(bits(t), bits(exp))
+    assert (t[:, 3] == 1.0).all()
+
+
+def test_preset_save_load_round_trip(tmp_path):
+    o = host.OpacityTF(128)
+    o.SetDataRange(3000)
+    o.AddControlPoint(30, 0.9)
+    o.AddControlPoint(90, 0.05)
+    p = str(tmp_path / "otf")
+    assert o.Save(p)
+    lines = open(p).read().split("\n")
+    assert lines[:7] == ["opacity", "resolution", "128", "data range", "3000", "control points number", "4"]
+    o2 = host.OpacityTF(16)
+    o2.Load(p)
+    assert o2.GetTextureResolution() == 128
+    assert o2.GetControlPoints() == o.GetControlPoints()
+    assert np.array_equal(bits(o2.table()), bits(o.table()))
+    c = host.ColorTF(64)
+    c.AddColorControlPoint(20, (0.2, 0.4, 0.6, 1.0))
+    pc = str(tmp_path / "ctf")
+    assert c.Save(pc)
+    c2 = host.ColorTF(8)
+    c2.Load(pc)
+    assert c2.GetTextureResolution() == 64
+    np.testing.assert_allclose(c2.table(), c.table(), atol=1e-6)  # text round trip of the control colours
+    o3 = host.OpacityTF(16)
+    o3.Load(pc)  # wrong type: ignored, state unchanged
+    assert o3.GetTextureResolution() == 16
+
+
+def test_remap_control_points_to_new_data_range(tmp_path):
+    """TransferFunction::RemapCP (TransferFunction.cpp:55-84): cp.x/(R-1) * oldRange -> density; clip if above the
+    new range; else int(density/newRange * (R-1))."""
+    o = host.OpacityTF(4096)
+    o.SetDataRange(2000)
+    assert o.RemapCP(2048.0, 0.7, 4000, 4096) == (-1.0, -1.0)       # density 2000.49 > 2000 -> clipped
+    assert o.RemapCP(2047.5, 0.7, 4000, 4096) == (4095.0, 0.7)      # density exactly 2000: kept, maps to the end
+    x, y = o.RemapCP(1000.0, 0.7, 3000, 4096)
+    assert (x, y) == (float(int((1000.0 / 4095 * 3000) / 2000 * 4095)), 0.7)
+    src = host.OpacityTF(4096)
+    src.SetDataRange(4000)
+    src.AddControlPoint(500, 0.0)
+    src.AddControlPoint(900, 1.0)
+    p = str(tmp_path / "bones")
+    src.Save(p)
+    o.Load(p, rescale=True)
+    cps = o.GetControlPoints()
+    assert cps[0] == (0.0, 0.0) and cps[1][0] == float(int((500 / 4095 * 4000) / 2000 * 4095))
+    assert all(0 <= c[0] <= 4095 for c in cps)
+
+
+def test_calibrate_on_mask_and_histogram():
+    n = 16
+    raw = np.full((n, n, n), 100, dtype=np.uint16)
+    raw[4:12, 4:12, 4:12] = 900
+    raw[0, 0, 0] = 1000
+    ct = host.VolumeFile.from_raw(raw)
+    m = np.zeros((n, n, n, 4), dtype=f32)
+    m[4:12, 4:12, 4:12, 0] = 1.0
+    mask = host.VolumeFile.from_vec4(m, 1)
+    tf = host.OpacityTF(1000)
+    tf.CalibrateOnMask(mask, ct, (1, 0, 0, 0))
+    cps = tf.GetControlPoints()
+    assert cps[0] == (0.0, 0.0) and cps[-1] == (999.0, 0.0)
+    assert (float(int(900 / 1000 * 1000)), 1.0) in cps
+    t = tf.table()
+    assert t[900] == 1.0 and t[0] == 0.0 and t[999] == 0.0 and 0.0 < t[450] < 1.0
+    h = tf.ActivateHistogram(ct)
+    assert h[100] > h[900] > 0 and h[500] == 0
+
+
+@pytest.mark.parametrize("pitch,yaw,dist", [(0.35, 0.6, 1.2), (0.0, 0.0, 5.0), (-1.0, 2.5, 0.8), (1.3, -3.0, 9.0)])
+def test_camera_matches_numpy_restatement(pitch, yaw, dist):
+    fov, aspect = math.radians(60.0), 1920 / 1080
+    cam = host.Camera(fov, aspect)
+    cam.SetOrbit(pitch, yaw, dist)
+    got = cam.get()
+    ref = hr.Camera(fov, aspect)
+    ref.pitch, ref.yaw, ref.distance = pitch, yaw, dist
+    view, proj, view_inv, proj_inv = ref.matrices()
+    np.testing.assert_allclose(got["view"], view, atol=2e-6)
+    np.testing.assert_allclose(got["proj"], proj, atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(got["view_inv"], view_inv, atol=2e-6)
+    np.testing.assert_allclose(got["proj_inv"], proj_inv, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["position"], ref.get_position(), atol=2e-6)
+    # view * view_inv = I, camera position = translation column of view_inv
+    prod = got["view_inv"].astype(np.float64) @ got["view"].astype(np.float64)
+    np.testing.assert_allclose(prod, np.eye(4), atol=1e-5)
+    np.testing.assert_allclose(got["view_inv"][3, :3], got["position"], atol=1e-6)
+
+
+def test_camera_interaction_rules():
+    cam = host.Camera(1.0, 1.5)
+    assert cam.get()["position"].tolist() == [0.0, 0.0, 5.0]   # default distance 5 along +z (Camera.h:64)
+    cam.SetZoomDistance(-10000.0)
+    assert abs(np.linalg.norm(cam.get()["position"]) - 0.1) < 1e-6   # clamp 0.1..10 (Camera.cpp:56)
+    cam.SetZoomDistance(1e9)
+    assert abs(np.linalg.norm(cam.get()["position"]) - 10.0) < 1e-5
+    cam.Rotate(100.0, 0.0)  # yaw += 100 * 0.005
+    ref = hr.Camera(1.0, 1.5)
+    ref.yaw, ref.distance = 0.5, 10.0
+    np.testing.assert_allclose(cam.get()["position"], ref.get_position(), atol=1e-5)
+
+
+def test_stepping_params():
+    assert hr.stepping_params(512, 512, 512)[1] == 886 and hr.stepping_params(64, 64, 64)[1] == 110
+    assert hr.stepping_params(1024, 100, 3)[1] == 1773 and hr.stepping_params(256, 256, 256)[1] == 443

@@ -27,9 +27,9 @@ TILE = 64
 # every symbol include/vr.h declares (tests check that the library exports each of them)
 ABI_SYMBOLS = [
     "vr_create", "vr_resize", "vr_destroy", "vr_last_error", "vr_abi_version", "vr_volume_upload",
-    "vr_volume_upload_device", "vr_tf_upload", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
+    "vr_volume_upload_device", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
-    "vr_last_timing", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_set_kernel_flavour",
+    "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_set_kernel_flavour",
 ]
 
 
@@ -77,6 +77,8 @@ def load() -> C.CDLL:
     lib.vr_volume_upload.argtypes = [vp, i32, vp, u16, u16, u16]
     lib.vr_volume_upload_device.argtypes = [vp, i32, vp, u16, u16, u16]
     lib.vr_tf_upload.argtypes = [vp, i32, vp, vp, u32]
+    lib.vr_tf_upload_opacity.argtypes = [vp, i32, vp, u32]
+    lib.vr_tf_upload_color.argtypes = [vp, i32, vp, u32]
     lib.vr_set_uniforms.argtypes = [vp, C.POINTER(Uniforms)]
     lib.vr_render.argtypes = [vp, i32]
     lib.vr_render_tiles.argtypes = [vp, i32, i32, i32]
@@ -87,6 +89,8 @@ def load() -> C.CDLL:
     lib.vr_download.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
     lib.vr_download_tiles.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     lib.vr_last_timing.argtypes = [vp, fp, fp]
+    lib.vr_kernel_times.argtypes = [vp, vp, i32]
+    lib.vr_reset_kernel_times.argtypes = [vp]
     lib.vr_frame_device_ptr.argtypes = [vp]
     lib.vr_frame_device_ptr.restype = vp
     lib.vr_last_covered_pixels.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -149,8 +153,11 @@ class Context:
 
     def tf_upload(self, slot: int, opacity: np.ndarray, color_rgba: np.ndarray):
         o, c = _f32(opacity), _f32(color_rgba)
-        assert c.size == 4 * o.size
-        self._chk(self.lib.vr_tf_upload(self.h, slot, o.ctypes.data, c.ctypes.data, o.size))
+        if c.size == 4 * o.size:
+            self._chk(self.lib.vr_tf_upload(self.h, slot, o.ctypes.data, c.ctypes.data, o.size))
+        else:  # the two textures of a pair may differ in resolution
+            self._chk(self.lib.vr_tf_upload_opacity(self.h, slot, o.ctypes.data, o.size))
+            self._chk(self.lib.vr_tf_upload_color(self.h, slot, c.ctypes.data, c.size // 4))
 
     def set_uniforms(self, u: Uniforms):
         self._chk(self.lib.vr_set_uniforms(self.h, C.byref(u)))
@@ -196,6 +203,14 @@ class Context:
         k, t = C.c_float(0), C.c_float(0)
         self._chk(self.lib.vr_last_timing(self.h, C.byref(k), C.byref(t)))
         return float(k.value), float(t.value)
+
+    def kernel_times(self, capacity: int = 256) -> np.ndarray:
+        out = np.zeros(capacity, dtype=np.float32)
+        n = self._chk(self.lib.vr_kernel_times(self.h, out.ctypes.data, capacity))
+        return out[:n].copy()
+
+    def reset_kernel_times(self):
+        self._chk(self.lib.vr_reset_kernel_times(self.h))
 
     def covered_pixels(self) -> int:
         n = C.c_uint64(0)

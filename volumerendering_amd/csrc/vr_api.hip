@@ -20,6 +20,12 @@ struct Timing {
     bool valid = false;
 };
 
+constexpr int kRing = 256;
+struct KernelRing {  // one (start, stop) event pair per render call, reused round-robin
+    hipEvent_t k0[kRing] = {}, k1[kRing] = {};
+    long long head = 0;  // total launches recorded since the last reset
+};
+
 }  // namespace
 
 struct vr_ctx {
@@ -41,6 +47,7 @@ struct vr_ctx {
     unsigned long long* d_counters = nullptr;  // [2]
     unsigned long long* h_counters = nullptr;  // pinned [2]
     Timing tm;
+    KernelRing ring;
     int flavour = 0;
     std::string err;
 };
@@ -130,7 +137,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         if (c->vol_bytes[i] > 0xFFFFFFFFull) off32 = false;
     }
     for (int i = 0; i < ntf; ++i)
-        if (!c->tf[i].opacity) return fail(c, VR_ERR_NOT_READY, "vr_render: TF slot " + std::to_string(i) + " is empty");
+        if (!c->tf[i].opacity || !c->tf[i].color)
+            return fail(c, VR_ERR_NOT_READY, "vr_render: TF slot " + std::to_string(i) + " is empty");
     if (c->u.steps_count < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: negative steps_count");
     VR_HIP(c, hipSetDevice(c->device));
 
@@ -184,7 +192,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     VR_HIP(c, hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), s));
     if (P.n_blocks > 0) {
         dim3 grid((unsigned)((P.n_blocks + 7) / 8 * 8));
-        if (record_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
+        const int slot = (int)(c->ring.head % kRing);
+        if (record_events) {
+            VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
+            VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
+        }
         switch (variant) {
         case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, grid, s, P); break;
         case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, grid, s, P); break;
@@ -194,7 +206,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         default: launch_variant<V_TF_CALIB>(off32, grid, s, P); break;
         }
         VR_HIP(c, hipGetLastError());
-        if (record_events) VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
+        if (record_events) {
+            VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
+            VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
+            ++c->ring.head;
+        }
     } else if (record_events) {
         VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
         VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
@@ -250,6 +266,9 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (!hip_ok(hipEventCreate(&c->tm.ev_k0), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_k1), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_end), "hipEventCreate")) return bail(VR_ERR_HIP);
+    for (int i = 0; i < kRing; ++i)
+        if (!hip_ok(hipEventCreate(&c->ring.k0[i]), "hipEventCreate") || !hip_ok(hipEventCreate(&c->ring.k1[i]), "hipEventCreate"))
+            return bail(VR_ERR_HIP);
     if (!hip_ok(hipMalloc(&c->d_counters, 2 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 2 * sizeof(unsigned long long), hipHostMallocDefault),
                 "hipHostMalloc"))
@@ -288,6 +307,10 @@ void vr_destroy(vr_ctx* c)
     if (c->d_present) (void)hipFree(c->d_present);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (int i = 0; i < kRing; ++i) {
+        if (c->ring.k0[i]) (void)hipEventDestroy(c->ring.k0[i]);
+        if (c->ring.k1[i]) (void)hipEventDestroy(c->ring.k1[i]);
+    }
     if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
     if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);
     if (c->tm.ev_k1) (void)hipEventDestroy(c->tm.ev_k1);
@@ -339,30 +362,51 @@ int vr_volume_upload_device(vr_ctx* c, int slot, const void* d_vec4_voxels, uint
     return volume_upload_common(c, slot, d_vec4_voxels, true, nx, ny, nz);
 }
 
-int vr_tf_upload(vr_ctx* c, int slot, const float* opacity, const float* color_rgba, uint32_t R)
+static int tf_upload_one(vr_ctx* c, int slot, const float* table, uint32_t R, bool is_color)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     if (slot < 0 || slot >= VR_MAX_TFS) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: bad slot");
-    if (!opacity || !color_rgba) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: table is NULL");
+    if (!table) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: table is NULL");
     if (R == 0 || R > (1u << 24)) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: bad resolution");
     VR_HIP(c, hipSetDevice(c->device));
     VR_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->tf[slot].res != (int)R) {
-        if (c->tf_opacity[slot]) (void)hipFree(c->tf_opacity[slot]);
-        if (c->tf_color[slot]) (void)hipFree(c->tf_color[slot]);
-        c->tf_opacity[slot] = nullptr;
-        c->tf_color[slot] = nullptr;
-        c->tf[slot] = DevTF{};
-        VR_HIP(c, hipMalloc(&c->tf_opacity[slot], R * sizeof(float)));
-        VR_HIP(c, hipMalloc(&c->tf_color[slot], R * sizeof(float4)));
+    if (is_color) {
+        if (c->tf[slot].res_c != (int)R) {
+            if (c->tf_color[slot]) (void)hipFree(c->tf_color[slot]);
+            c->tf_color[slot] = nullptr;
+            c->tf[slot].color = nullptr;
+            c->tf[slot].res_c = 0;
+            VR_HIP(c, hipMalloc(&c->tf_color[slot], R * sizeof(float4)));
+        }
+        VR_HIP(c, hipMemcpyAsync(c->tf_color[slot], table, R * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        VR_HIP(c, hipStreamSynchronize(c->stream));
+        c->tf[slot].color = c->tf_color[slot];
+        c->tf[slot].res_c = (int)R;
+    } else {
+        if (c->tf[slot].res_o != (int)R) {
+            if (c->tf_opacity[slot]) (void)hipFree(c->tf_opacity[slot]);
+            c->tf_opacity[slot] = nullptr;
+            c->tf[slot].opacity = nullptr;
+            c->tf[slot].res_o = 0;
+            VR_HIP(c, hipMalloc(&c->tf_opacity[slot], R * sizeof(float)));
+        }
+        VR_HIP(c, hipMemcpyAsync(c->tf_opacity[slot], table, R * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        VR_HIP(c, hipStreamSynchronize(c->stream));
+        c->tf[slot].opacity = c->tf_opacity[slot];
+        c->tf[slot].res_o = (int)R;
     }
-    VR_HIP(c, hipMemcpyAsync(c->tf_opacity[slot], opacity, R * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    VR_HIP(c, hipMemcpyAsync(c->tf_color[slot], color_rgba, R * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    VR_HIP(c, hipStreamSynchronize(c->stream));
-    c->tf[slot].opacity = c->tf_opacity[slot];
-    c->tf[slot].color = c->tf_color[slot];
-    c->tf[slot].res = (int)R;
     return VR_OK;
+}
+
+int vr_tf_upload_opacity(vr_ctx* c, int slot, const float* opacity, uint32_t R) { return tf_upload_one(c, slot, opacity, R, false); }
+int vr_tf_upload_color(vr_ctx* c, int slot, const float* color_rgba, uint32_t R) { return tf_upload_one(c, slot, color_rgba, R, true); }
+
+int vr_tf_upload(vr_ctx* c, int slot, const float* opacity, const float* color_rgba, uint32_t R)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!opacity || !color_rgba) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: table is NULL");
+    int rc = tf_upload_one(c, slot, opacity, R, false);
+    return rc != VR_OK ? rc : tf_upload_one(c, slot, color_rgba, R, true);
 }
 
 int vr_set_uniforms(vr_ctx* c, const vr_uniforms* u)
@@ -472,6 +516,28 @@ int vr_last_timing(vr_ctx* c, float* kernel_ms, float* total_ms)
     VR_HIP(c, hipEventElapsedTime(&t, c->tm.ev_begin, c->tm.ev_end));
     if (kernel_ms) *kernel_ms = k;
     if (total_ms) *total_ms = t;
+    return VR_OK;
+}
+
+int vr_kernel_times(vr_ctx* c, float* out_ms, int capacity)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!out_ms || capacity < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_kernel_times: bad arguments");
+    VR_HIP(c, hipSetDevice(c->device));
+    long long have = c->ring.head < kRing ? c->ring.head : kRing;
+    int n = (int)(have < capacity ? have : capacity);
+    for (int i = 0; i < n; ++i) {
+        int slot = (int)((c->ring.head - n + i) % kRing);
+        VR_HIP(c, hipEventSynchronize(c->ring.k1[slot]));
+        VR_HIP(c, hipEventElapsedTime(&out_ms[i], c->ring.k0[slot], c->ring.k1[slot]));
+    }
+    return n;
+}
+
+int vr_reset_kernel_times(vr_ctx* c)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    c->ring.head = 0;
     return VR_OK;
 }
 

@@ -16,9 +16,9 @@ struct DevVolume {
 };
 
 struct DevTF {
-    const float* opacity;  // R32Float[res]     (OpacityTf.cpp:25-26)
-    const float4* color;   // RGBA32Float[res]  (ColorTf.cpp:23-24)
-    int res;
+    const float* opacity;  // R32Float[res_o]     (OpacityTf.cpp:25-26)
+    const float4* color;   // RGBA32Float[res_c]  (ColorTf.cpp:23-24)
+    int res_o, res_c;
 };
 
 // Kernel argument block (passed by value, lives in SGPRs / kernarg segment).

@@ -190,15 +190,20 @@ struct TfSample {
 };
 __device__ __forceinline__ TfSample tf_lookup(const DevTF& tf, float d)
 {
-    float x = d * (float)tf.res - 0.5f;
-    float x0 = floorf(x);
-    float f = x - x0;
-    int i0 = clampi((int)x0, 0, tf.res - 1), i1 = clampi((int)x0 + 1, 0, tf.res - 1);
-    float o0 = tf.opacity[i0], o1 = tf.opacity[i1];
-    float4 c0 = tf.color[i0], c1 = tf.color[i1];
+    // the opacity and the colour texture are separate 1-D textures, each with its own resolution
+    float xo = d * (float)tf.res_o - 0.5f;
+    float xo0 = floorf(xo);
+    float fo = xo - xo0;
+    int o0i = clampi((int)xo0, 0, tf.res_o - 1), o1i = clampi((int)xo0 + 1, 0, tf.res_o - 1);
+    float xc = d * (float)tf.res_c - 0.5f;
+    float xc0 = floorf(xc);
+    float fc = xc - xc0;
+    int c0i = clampi((int)xc0, 0, tf.res_c - 1), c1i = clampi((int)xc0 + 1, 0, tf.res_c - 1);
+    float o0 = tf.opacity[o0i], o1 = tf.opacity[o1i];
+    float4 c0 = tf.color[c0i], c1 = tf.color[c1i];
     TfSample s;
-    s.opacity = lerpf(o0, o1, f);
-    s.rgb = mk3(lerpf(c0.x, c1.x, f), lerpf(c0.y, c1.y, f), lerpf(c0.z, c1.z, f));
+    s.opacity = lerpf(o0, o1, fo);
+    s.rgb = mk3(lerpf(c0.x, c1.x, fc), lerpf(c0.y, c1.y, fc), lerpf(c0.z, c1.z, fc));
     return s;
 }
 
