@@ -82,7 +82,8 @@ def cpu_baseline(app, capi, variant, vols, W, H, budget_s=15.0):
     import host_ref as hr
     import oracle_binding as ob
 
-    cores = os.cpu_count() or 1
+    # threads actually used: the CPUs this process may run on, capped at the GPU box's per-GPU CPU share
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     u = app.uniforms()
     uo = hr.Uniforms.from_buffer_copy(bytes(u))
     volumes = [v.data() for v in vols]

@@ -36,8 +36,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    try:  # make is a no-op when the library is newer than its sources
         build()
+    except Exception:
+        if not os.path.exists(LIB_PATH):
+            raise
     lib = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int
     u64p = C.POINTER(C.c_uint64)
