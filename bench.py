@@ -49,10 +49,12 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_scene(app, host, synth, capi, workload, tf_kind):
+def build_scene(app, host, synth, capi, workload, tf_kind, vol_n=0):
     """Generates the synthetic inputs, runs the reference's data-prep order through the C++ host classes and
     starts the scene on `app` (uploads happen here, outside any timed region)."""
     n, W, H, vname = WORKLOADS[workload]
+    full_n = n
+    n = vol_n or n
     variant = capi.VARIANT_NAMES.index(vname)
     t0 = time.time()
     raw = synth.sphere_raw_fast(n) if workload == "C1" else synth.ct_phantom_raw_fast(n)
@@ -70,6 +72,8 @@ def build_scene(app, host, synth, capi, workload, tf_kind):
             otf.SetControlPoint(1, otf.GetTextureResolution() - 1, 0.002)
     cam = app.camera()
     cam.SetOrbit(0.35, 0.6, 1.2)
+    if vol_n:
+        app.set_params(steps_count=int(math.sqrt(3) * full_n), step_size=1.0 / full_n)
     app.OnUpdate()
     log(f"[bench] scene {workload} ({vname}, {n}^3, {W}x{H}, tf={tf_kind}) ready in {time.time() - t0:.1f}s")
     return variant, vols
@@ -117,6 +121,7 @@ def main():
     ap.add_argument("--tf", default="default", choices=["default", "thin"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flavour", type=int, default=0)
+    ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
     args = ap.parse_args()
 
     import torch
@@ -139,7 +144,7 @@ def main():
 
     n, W, H, vname = WORKLOADS[args.workload]
     app = host.Application(W, H, local_rank)
-    variant, vols = build_scene(app, host, synth, capi, args.workload, args.tf)
+    variant, vols = build_scene(app, host, synth, capi, args.workload, args.tf, args.vol_n)
     ctx = app.context()
     if args.flavour:
         ctx.set_kernel_flavour(args.flavour)
@@ -179,27 +184,29 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
 
-    my_samples = ctx.samples()       # composited samples of this rank's share of the last frame
-    my_covered = ctx.covered_pixels()
+    # composited samples / covered pixels / samples whose voxels were fetched, for this rank's share of the frame
+    my_samples, my_covered, my_fetched = ctx.counters()
     ktimes = ctx.kernel_times(min(args.steps, 256))
     kernel_ms = float(np.mean(ktimes)) if len(ktimes) else float("nan")
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([my_samples, my_covered], dtype=torch.int64, device="cuda")
+        s = torch.tensor([my_samples, my_covered, my_fetched], dtype=torch.int64, device="cuda")
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        total_samples, covered = int(s[0].item()), int(s[1].item())
+        total_samples, covered, total_fetched = int(s[0].item()), int(s[1].item()), int(s[2].item())
     else:
-        total_samples, covered = my_samples, my_covered
+        total_samples, covered, total_fetched = my_samples, my_covered, my_fetched
 
     ms_per_step = dt / args.steps * 1e3
     value = total_samples / (dt / args.steps) / 1e9
     bs = BYTES_PER_SAMPLE[vname]
-    # dominant kernel = march_kernel; algorithmic bytes per launch = this rank's samples * B_s + the 16 B/pixel
-    # frame write of the pixels it owns (ray set-up is fused into the kernel: no ray-end image is read)
+    # dominant kernel = march_kernel; algorithmic bytes per launch = the samples this rank actually FETCHED * B_s
+    # (samples the exact empty-space test skips need no voxel bytes and are not counted here, although they are
+    # composited samples of the metric) + the 16 B/pixel frame write of the pixels it owns (ray set-up is fused
+    # into the kernel: no ray-end image is read)
     owned_px = W * H if world == 1 else ctx.tile_count(rank, world) * capi.TILE * capi.TILE
-    alg_bytes = my_samples * bs + 16 * owned_px
+    alg_bytes = my_fetched * bs + 16 * owned_px
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms and kernel_ms > 0 else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
@@ -220,7 +227,8 @@ def main():
             "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, "
                         f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
             "partition": "single GPU" if world == 1 else f"64x64 image tiles interleaved over {world} GPUs + RCCL gather",
-            "composited_samples_per_frame": total_samples, "covered_pixels": covered,
+            "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
+            "covered_pixels": covered, "kernel_flavour": args.flavour,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

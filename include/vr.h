@@ -194,8 +194,13 @@ void* vr_frame_device_ptr(vr_ctx* ctx);
 /* Number of pixels that produced a fragment in the last render (front face hit & not clipped). */
 int vr_last_covered_pixels(vr_ctx* ctx, uint64_t* covered);
 
-/* Kernel flavour for A/B measurements: 0 = default (best), >0 = named alternatives listed in
- * DESIGN.md.  All flavours are bit-identical in output.                                          */
+/* Counters of the last render: out[0] = composited samples (blends the reference's loop executes),
+ * out[1] = covered pixels, out[2] = samples whose voxels were actually fetched (= out[0] minus the
+ * samples the exact empty-space test proved to be the identity).                                 */
+int vr_last_counters(vr_ctx* ctx, uint64_t out[3]);
+
+/* Kernel flavour for A/B measurements: 0 = default (best), 1 = no empty-space skipping.  All
+ * flavours are bit-identical in output and in the composited-sample count.                       */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 
 #ifdef __cplusplus

@@ -160,3 +160,88 @@ def test_error_behaviour(ctx):
     with pytest.raises(capi.VrError):
         c.tf_upload(5, np.zeros(4, f32), np.zeros((4, 4), f32))
     c.close()
+
+
+# ---------------------------------------------------------------------------------------------- empty-space skipping
+def zero_prefix_tf(res, zeros, top=0.3):
+    """opacity: `zeros` exact zeros, then a ramp up to `top`."""
+    o = np.zeros(res, dtype=f32)
+    if zeros < res:
+        o[zeros:] = np.linspace(top / (res - zeros), top, res - zeros, dtype=f32)
+    return o, hr.default_color_tf(res)
+
+
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.THREE_FILES])
+@pytest.mark.parametrize("zeros", [0, 1, 2, 9, 17, 40, 64])
+def test_empty_space_skipping_is_exact(ctx, variant, zeros):
+    """Skipped samples are exactly the identity: flavour 0 (skipping) == flavour 1 (plain) == oracle, bit for bit,
+    for every length of the opacity table's zero prefix (incl. none, and all-zero)."""
+    W, H, n = 96, 64, 24
+    vols, tfs = vt.scene(variant, n=n)
+    tfs[0] = zero_prefix_tf(64, zeros)
+    step, count = hr.stepping_params(n, n, n)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=0.9, pitch=-0.3)
+    ctx.set_kernel_flavour(0)
+    frag, n_s = check(ctx, variant, u, vols, tfs, W, H)
+    comp0, cov0, fetched0 = ctx.counters()
+    ctx.set_kernel_flavour(1)
+    frag1, n_s1 = check(ctx, variant, u, vols, tfs, W, H)
+    comp1, cov1, fetched1 = ctx.counters()
+    ctx.set_kernel_flavour(0)
+    assert np.array_equal(vt.bits(frag), vt.bits(frag1)) and comp0 == comp1 == n_s and cov0 == cov1
+    assert fetched1 == comp1          # the plain kernel fetches every composited sample
+    if zeros == 0:
+        assert fetched0 == comp0      # opacity[0] != 0: nothing may be skipped
+    else:
+        assert fetched0 < comp0       # the phantom's air (density exactly 0) is skipped
+    if zeros >= 40:
+        assert fetched0 < 0.5 * comp0
+
+
+def test_skipping_with_hostile_values(ctx):
+    """NaN / inf / negative densities, non-finite colour tables and lights: skipping must either stay exact or
+    switch itself off."""
+    W, H, n = 64, 48, 16
+    rng = np.random.default_rng(3)
+    v = np.zeros((n, n, n, 4), dtype=f32)
+    v[4:12, 4:12, 4:12, 3] = rng.random((8, 8, 8), dtype=f32) * f32(0.5)
+    v[..., :3] = rng.standard_normal((n, n, n, 3)).astype(f32)
+    v[2, 2, 2, 3] = -0.25
+    v[13, 3, 3, 3] = np.inf
+    v[3, 13, 13, 3] = np.nan
+    step, count = hr.stepping_params(n, n, n)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
+    tf = zero_prefix_tf(32, 3)
+    for variant in (capi.BASIC, capi.LIGHT):
+        frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
+        ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
+        assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref
+    # non-finite colour entry: 0 * inf = NaN would differ from a skipped sample -> skipping is disabled
+    c = hr.default_color_tf(32).copy()
+    c[0, 1] = np.inf
+    frag, _, ns = vt.gpu_render(ctx, capi.BASIC, u, [v], [(tf[0], c)])
+    ref, n_ref, _ = ob.render(capi.BASIC, u, [v], [(tf[0], c)], W, H, nthreads=8)
+    assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref
+    assert ctx.counters()[2] == ns
+    # non-finite light
+    u2 = hr.make_uniforms(W, H, steps_count=count, step_size=step, light_diffuse=(np.inf, 1.0, 1.0, 1.0))
+    frag, _, ns = vt.gpu_render(ctx, capi.LIGHT, u2, [v], [tf])
+    ref, n_ref, _ = ob.render(capi.LIGHT, u2, [v], [tf], W, H, nthreads=8)
+    assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref
+    assert ctx.counters()[2] == ns
+
+
+def test_skipping_brick_boundaries(ctx):
+    """A single non-zero voxel at each position of the 9-voxel brick apron must keep its neighbours' cells live."""
+    W, H, n = 80, 60, 24
+    tf = zero_prefix_tf(64, 1, top=0.9)
+    step, count = hr.stepping_params(n, n, n)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=0.3, pitch=0.2)
+    for pos in [(7, 7, 7), (8, 8, 8), (0, 0, 0), (23, 23, 23), (15, 16, 7), (8, 0, 23)]:
+        v = np.zeros((n, n, n, 4), dtype=f32)
+        v[pos[2], pos[1], pos[0], 3] = 1.0
+        frag, _, ns = vt.gpu_render(ctx, capi.BASIC, u, [v], [tf])
+        ref, n_ref, _ = ob.render(capi.BASIC, u, [v], [tf], W, H, nthreads=8)
+        assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref, pos
+        assert ref[..., 3].max() > 0
+        assert ctx.counters()[2] < ns

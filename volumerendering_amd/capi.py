@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "vr_create", "vr_resize", "vr_destroy", "vr_last_error", "vr_abi_version", "vr_volume_upload",
     "vr_volume_upload_device", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
-    "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_set_kernel_flavour",
+    "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour",
 ]
 
 
@@ -94,6 +94,7 @@ def load() -> C.CDLL:
     lib.vr_frame_device_ptr.argtypes = [vp]
     lib.vr_frame_device_ptr.restype = vp
     lib.vr_last_covered_pixels.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.vr_last_counters.argtypes = [vp, C.POINTER(C.c_uint64 * 3)]
     lib.vr_set_kernel_flavour.argtypes = [vp, i32]
     _lib = lib
     return lib
@@ -216,6 +217,12 @@ class Context:
         n = C.c_uint64(0)
         self._chk(self.lib.vr_last_covered_pixels(self.h, C.byref(n)))
         return int(n.value)
+
+    def counters(self):
+        """(composited samples, covered pixels, samples actually fetched) of the last render."""
+        out = (C.c_uint64 * 3)()
+        self._chk(self.lib.vr_last_counters(self.h, C.byref(out)))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def frame_device_ptr(self) -> int:
         return int(self.lib.vr_frame_device_ptr(self.h) or 0)

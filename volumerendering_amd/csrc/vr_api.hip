@@ -34,6 +34,10 @@ struct vr_ctx {
     hipStream_t stream = nullptr;
     DevVolume vol[VR_MAX_VOLUMES] = {};
     size_t vol_bytes[VR_MAX_VOLUMES] = {};
+    float* vol_brick_max[VR_MAX_VOLUMES] = {};  // per-brick max density (empty-space skipping)
+    int tf_zero_prefix[VR_MAX_TFS] = {-1, -1};  // zero prefix of each opacity table, -1 if none / not finite
+    bool tf_color_finite[VR_MAX_TFS] = {false, false};
+    bool tf_opacity_finite[VR_MAX_TFS] = {false, false};
     DevTF tf[VR_MAX_TFS] = {};
     float* tf_opacity[VR_MAX_TFS] = {};
     float4* tf_color[VR_MAX_TFS] = {};
@@ -44,8 +48,8 @@ struct vr_ctx {
     size_t tiles_cap = 0;       // in float4
     int last_tiles = 0;         // tiles rendered by the last vr_render_tiles
     uint32_t* d_present = nullptr;
-    unsigned long long* d_counters = nullptr;  // [2]
-    unsigned long long* h_counters = nullptr;  // pinned [2]
+    unsigned long long* d_counters = nullptr;  // [3] composited, covered, fetched
+    unsigned long long* h_counters = nullptr;  // pinned [3]
     Timing tm;
     KernelRing ring;
     int flavour = 0;
@@ -116,10 +120,27 @@ int alloc_frame(vr_ctx* c)
 template <int V>
 void launch_variant(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
 {
+    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES);
+    if constexpr (kCanSkip) {
+        if (P.brick_max) {
+            if (off32)
+                hipLaunchKernelGGL((march_kernel<V, true, true>), grid, dim3(256), 0, s, P);
+            else
+                hipLaunchKernelGGL((march_kernel<V, false, true>), grid, dim3(256), 0, s, P);
+            return;
+        }
+    }
     if (off32)
-        hipLaunchKernelGGL((march_kernel<V, true>), grid, dim3(256), 0, s, P);
+        hipLaunchKernelGGL((march_kernel<V, true, false>), grid, dim3(256), 0, s, P);
     else
-        hipLaunchKernelGGL((march_kernel<V, false>), grid, dim3(256), 0, s, P);
+        hipLaunchKernelGGL((march_kernel<V, false, false>), grid, dim3(256), 0, s, P);
+}
+
+bool all_finite(const float* v, int n)
+{
+    for (int i = 0; i < n; ++i)
+        if (!(v[i] - v[i] == 0.0f)) return false;
+    return true;
 }
 
 // Enqueue one render on `s`.  out == nullptr -> ctx-owned buffer.
@@ -171,6 +192,19 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     P.packed = packed ? 1 : 0;
     P.n_blocks = P.n_tiles * kBlocksPerTile;
     P.counters = c->d_counters;
+    // exact empty-space skipping: only for the shaders whose opacity is the CT table value alone, only when a
+    // zero-opacity sample is provably the identity (finite colour table and light), and unless flavour 1 asks
+    // for the plain kernel
+    const bool skip_variant = variant == VR_VARIANT_BASIC || variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_THREE_FILES;
+    if (skip_variant && c->flavour != 1 && c->vol_brick_max[0] && c->tf_zero_prefix[0] >= 0 && c->tf_color_finite[0] &&
+        (variant != VR_VARIANT_THREE_FILES || (c->tf_color_finite[1] && c->tf_opacity_finite[1])) &&
+        all_finite(c->u.light_pos, 12)) {
+        P.brick_max = c->vol_brick_max[0];
+        P.bnx = (c->vol[0].nx + 7) >> kBrickShift;
+        P.bny = (c->vol[0].ny + 7) >> kBrickShift;
+        P.bnz = (c->vol[0].nz + 7) >> kBrickShift;
+        P.tf_zero_prefix = c->tf_zero_prefix[0];
+    }
 
     if (packed && !out) {
         size_t need = (size_t)P.n_tiles * kTile * kTile;
@@ -189,7 +223,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     c->last_tiles = packed ? P.n_tiles : 0;
 
     if (record_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
-    VR_HIP(c, hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), s));
+    VR_HIP(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), s));
     if (P.n_blocks > 0) {
         dim3 grid((unsigned)((P.n_blocks + 7) / 8 * 8));
         const int slot = (int)(c->ring.head % kRing);
@@ -215,7 +249,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
         VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
     }
-    VR_HIP(c, hipMemcpyAsync(c->h_counters, c->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    VR_HIP(c, hipMemcpyAsync(c->h_counters, c->d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     if (record_events) {
         VR_HIP(c, hipEventRecord(c->tm.ev_end, s));
         c->tm.valid = true;
@@ -269,11 +303,11 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     for (int i = 0; i < kRing; ++i)
         if (!hip_ok(hipEventCreate(&c->ring.k0[i]), "hipEventCreate") || !hip_ok(hipEventCreate(&c->ring.k1[i]), "hipEventCreate"))
             return bail(VR_ERR_HIP);
-    if (!hip_ok(hipMalloc(&c->d_counters, 2 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
-    if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 2 * sizeof(unsigned long long), hipHostMallocDefault),
+    if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 3 * sizeof(unsigned long long), hipHostMallocDefault),
                 "hipHostMalloc"))
         return bail(VR_ERR_HIP);
-    c->h_counters[0] = c->h_counters[1] = 0;
+    c->h_counters[0] = c->h_counters[1] = c->h_counters[2] = 0;
     rc = alloc_frame(c);
     if (rc != VR_OK) return bail(rc);
     *out = c;
@@ -298,6 +332,8 @@ void vr_destroy(vr_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
         if (c->vol[i].data) (void)hipFree(const_cast<float4*>(c->vol[i].data));
+    for (int i = 0; i < VR_MAX_VOLUMES; ++i)
+        if (c->vol_brick_max[i]) (void)hipFree(c->vol_brick_max[i]);
     for (int i = 0; i < VR_MAX_TFS; ++i) {
         if (c->tf_opacity[i]) (void)hipFree(c->tf_opacity[i]);
         if (c->tf_color[i]) (void)hipFree(c->tf_color[i]);
@@ -349,6 +385,16 @@ static int volume_upload_common(vr_ctx* c, int slot, const void* src, bool src_i
     c->vol[slot].ny = ny;
     c->vol[slot].nz = nz;
     c->vol_bytes[slot] = bytes;
+    // per-brick density maxima for the exact empty-space test (one pass over the volume, at upload time)
+    if (c->vol_brick_max[slot]) (void)hipFree(c->vol_brick_max[slot]);
+    c->vol_brick_max[slot] = nullptr;
+    const int bnx = (nx + 7) >> kBrickShift, bny = (ny + 7) >> kBrickShift, bnz = (nz + 7) >> kBrickShift;
+    const size_t nbricks = (size_t)bnx * bny * bnz;
+    VR_HIP(c, hipMalloc(&c->vol_brick_max[slot], nbricks * sizeof(float)));
+    hipLaunchKernelGGL(brick_max_kernel, dim3((unsigned)nbricks), dim3(64), 0, c->stream, d, (int)nx, (int)ny, (int)nz, bnx,
+                       bny, c->vol_brick_max[slot]);
+    VR_HIP(c, hipGetLastError());
+    VR_HIP(c, hipStreamSynchronize(c->stream));
     return VR_OK;
 }
 
@@ -382,6 +428,7 @@ static int tf_upload_one(vr_ctx* c, int slot, const float* table, uint32_t R, bo
         VR_HIP(c, hipStreamSynchronize(c->stream));
         c->tf[slot].color = c->tf_color[slot];
         c->tf[slot].res_c = (int)R;
+        c->tf_color_finite[slot] = all_finite(table, (int)(4 * R));
     } else {
         if (c->tf[slot].res_o != (int)R) {
             if (c->tf_opacity[slot]) (void)hipFree(c->tf_opacity[slot]);
@@ -394,6 +441,11 @@ static int tf_upload_one(vr_ctx* c, int slot, const float* table, uint32_t R, bo
         VR_HIP(c, hipStreamSynchronize(c->stream));
         c->tf[slot].opacity = c->tf_opacity[slot];
         c->tf[slot].res_o = (int)R;
+        int z = -1;
+        c->tf_opacity_finite[slot] = all_finite(table, (int)R);
+        if (c->tf_opacity_finite[slot])
+            while (z + 1 < (int)R && table[z + 1] == 0.0f) ++z;
+        c->tf_zero_prefix[slot] = z;
     }
     return VR_OK;
 }
@@ -552,10 +604,21 @@ int vr_last_covered_pixels(vr_ctx* c, uint64_t* covered)
     return VR_OK;
 }
 
+int vr_last_counters(vr_ctx* c, uint64_t out[3])
+{
+    if (!c || !out) return VR_ERR_INVALID_ARG;
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    out[0] = c->h_counters[0];
+    out[1] = c->h_counters[1];
+    out[2] = c->h_counters[2];
+    return VR_OK;
+}
+
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour != 0) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour != 0 && flavour != 1) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

@@ -9,6 +9,7 @@ namespace vr {
 constexpr int kTile = 64;        // multi-GPU ownership granule (pixels)
 constexpr int kBlockEdge = 16;   // one 256-thread workgroup = 16x16 pixels = four 8x8 wave packets
 constexpr int kBlocksPerTile = (kTile / kBlockEdge) * (kTile / kBlockEdge);
+constexpr int kBrickShift = 3;    // empty-space bricks: 8x8x8 base cells
 
 struct DevVolume {
     const float4* data;  // reference layout: x fastest, (k*ny + j)*nx + i   (VolumeFile.cpp:306)
@@ -38,8 +39,13 @@ struct MarchParams {
     int rank, world, tiles_x, tiles_y, n_tiles;
     int packed;              // 0: write frame[y*W+x]; 1: write packed tiles
     int n_blocks;            // logical blocks = n_tiles * kBlocksPerTile (grid is padded to a multiple of 8)
+    // exact empty-space skipping (BASIC / LIGHT / THREE_FILES): per-brick maximum density of vol[0] over the
+    // 9x9x9 voxels an 8x8x8 block of base cells can touch, and the length of the opacity table's zero prefix
+    const float* brick_max;  // nullptr = disabled
+    int bnx, bny, bnz;       // bricks per axis
+    int tf_zero_prefix;      // largest Z with opacity[0..Z] == 0 exactly (-1: none)
     float4* out;
-    unsigned long long* counters;  // [0] composited samples, [1] covered pixels
+    unsigned long long* counters;  // [0] composited samples, [1] covered pixels, [2] samples actually fetched
 };
 
 }  // namespace vr

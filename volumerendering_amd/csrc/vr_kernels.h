@@ -401,12 +401,33 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
     return s;
 }
 
-template <int V, bool OFF32>
+// Exact empty-space test for the 8x8x8-cell brick that contains the base cell of p (vol[0]).
+// A brick whose maximum density bm (over every voxel its cells can touch) maps into the zero prefix of the
+// opacity table yields opacity == 0 exactly for every sample inside it, and blending (rgb*0, 0) leaves dst
+// bit-identical (rgb is finite: the host checks tables and light).  Interpolated densities can exceed bm by a
+// few ulps, which moves the table index by at most one: hence the +2 (floor + 1 neighbour + 1 margin).
+// bm <= 0 (all-zero / negative cells) only ever addresses opacity[0].  NaN bm fails every comparison -> active.
+__device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
+{
+    const DevVolume& v = P.vol[0];
+    int i0 = clampi((int)floorf(p.x * (float)v.nx - 0.5f), 0, v.nx - 1);
+    int j0 = clampi((int)floorf(p.y * (float)v.ny - 0.5f), 0, v.ny - 1);
+    int k0 = clampi((int)floorf(p.z * (float)v.nz - 0.5f), 0, v.nz - 1);
+    return ((k0 >> kBrickShift) * P.bny + (j0 >> kBrickShift)) * P.bnx + (i0 >> kBrickShift);
+}
+__device__ __forceinline__ bool brick_inert(const MarchParams& P, int bid)
+{
+    float bm = P.brick_max[bid];
+    if (bm <= 0.0f) return P.tf_zero_prefix >= 0;
+    return floorf(bm * (float)P.tf[0].res_o - 0.5f) + 2.0f <= (float)P.tf_zero_prefix;
+}
+
+template <int V, bool OFF32, bool SKIP>
 __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
 {
     PixelSlot slot = map_pixel(P);
     float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    unsigned blends = 0, covered = 0;
+    unsigned blends = 0, covered = 0, fetched = 0;
 
     if (slot.active) {
         Ray ray = setup_ray(P, slot.px, slot.py);
@@ -445,11 +466,25 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                 f3 w = ray.world0;
                 const float bx0 = P.bmin[0], by0 = P.bmin[1], bz0 = P.bmin[2];
                 const float bx1 = P.bmax[0], by1 = P.bmax[1], bz1 = P.bmax[2];
+                int cur_brick = -1;
+                bool cur_inert = false;
                 for (int i = 0; i < P.steps_count; ++i) {
                     bool inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
                     if (inb) {
-                        sample_and_blend<V, OFF32>(P, p, w, dst);
-                        ++blends;
+                        bool inert = false;
+                        if constexpr (SKIP) {
+                            int bid = brick_of(P, p);
+                            if (bid != cur_brick) {  // one 4-byte lookup per brick entered, not per step
+                                cur_brick = bid;
+                                cur_inert = brick_inert(P, bid);
+                            }
+                            inert = cur_inert;
+                        }
+                        if (!inert) {
+                            sample_and_blend<V, OFF32>(P, p, w, dst);
+                            ++fetched;
+                        }
+                        ++blends;  // the reference's blend executes here; with opacity exactly 0 it is the identity
                         if (!can_blend<V>(dst.w)) break;  // cut-off reached: no later iteration can blend
                     } else {
                         // p moves monotonically per component: once past the far bound it never returns
@@ -474,10 +509,38 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
     unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) packed_cnt += __shfl_down(packed_cnt, off, 64);
+    unsigned long long fetched_cnt = fetched;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fetched_cnt += __shfl_down(fetched_cnt, off, 64);
     if ((threadIdx.x & 63) == 0 && packed_cnt != 0) {
         atomicAdd(&P.counters[0], packed_cnt & ((1ull << 40) - 1));
         atomicAdd(&P.counters[1], packed_cnt >> 40);
+        if (fetched_cnt) atomicAdd(&P.counters[2], fetched_cnt);
     }
+}
+
+// One wavefront per brick: maximum of .a over the voxels [8b, min(8b+8, n-1)]^3 (NaN if any voxel is NaN).
+__global__ __launch_bounds__(64) void brick_max_kernel(const float4* __restrict__ vol, int nx, int ny, int nz, int bnx,
+                                                       int bny, float* __restrict__ out)
+{
+    const int b = blockIdx.x;
+    const int bx = b % bnx, by = (b / bnx) % bny, bz = b / (bnx * bny);
+    const int x0 = bx << kBrickShift, y0 = by << kBrickShift, z0 = bz << kBrickShift;
+    const int ex = min(9, nx - x0), ey = min(9, ny - y0), ez = min(9, nz - z0);
+    float m = -INFINITY;
+    bool has_nan = false;
+    for (int t = threadIdx.x; t < ex * ey * ez; t += 64) {
+        int lx = t % ex, ly = (t / ex) % ey, lz = t / (ex * ey);
+        float a = vol[((size_t)(z0 + lz) * ny + (y0 + ly)) * nx + (x0 + lx)].w;
+        if (a != a) has_nan = true;
+        else if (a > m) m = a;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_down(m, off, 64));
+        has_nan = has_nan || (__shfl_down((int)has_nan, off, 64) != 0);
+    }
+    if (threadIdx.x == 0) out[b] = has_nan ? NAN : m;
 }
 
 // ------------------------------------------------------------------------------------------------ aux kernels
