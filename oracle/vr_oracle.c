@@ -34,6 +34,23 @@ static void normalize3(const float a[3], float out[3])
 static float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
 static float lerpf(float a, float b, float t) { return a + (b - a) * t; }
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* f32 -> i32 conversion is SATURATING with NaN -> 0 (WGSL clamps the value to the target range; C leaves the
+ * out-of-range case undefined).  Only reachable with non-finite voxel data. */
+static int f2i(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)x;
+}
+/* texel pair of a clamp-to-edge linear fetch: i0 = clamp(t, 0, n-1), i1 = clamp(t+1, 0, n-1), t = f2i(floor(x)) */
+static void texel_pair(float x0, int n, int* i0, int* i1)
+{
+    int t = f2i(x0);
+    if (t > n - 1) t = n - 1; /* limit from above first: t + 1 cannot overflow */
+    *i0 = clampi(t, 0, n - 1);
+    *i1 = clampi(t + 1, 0, n - 1);
+}
 
 /* column-major mat4 * vec4, summed left to right */
 static void mat4_mul_vec4(const float m[16], const float v[4], float out[4])
@@ -93,9 +110,10 @@ static void tex3_linear(const vro_volume* v, const float p[3], float out[4])
     float z = p[2] * (float)v->nz - 0.5f;
     float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
     float fx = x - x0, fy = y - y0, fz = z - z0;
-    int i0 = clampi((int)x0, 0, v->nx - 1), i1 = clampi((int)x0 + 1, 0, v->nx - 1);
-    int j0 = clampi((int)y0, 0, v->ny - 1), j1 = clampi((int)y0 + 1, 0, v->ny - 1);
-    int k0 = clampi((int)z0, 0, v->nz - 1), k1 = clampi((int)z0 + 1, 0, v->nz - 1);
+    int i0, i1, j0, j1, k0, k1;
+    texel_pair(x0, v->nx, &i0, &i1);
+    texel_pair(y0, v->ny, &j0, &j1);
+    texel_pair(z0, v->nz, &k0, &k1);
     const float* d = v->vec4;
     int64_t nx = v->nx, ny = v->ny;
     const float* v000 = d + 4 * ((k0 * ny + j0) * nx + i0);
@@ -120,9 +138,9 @@ static void tex3_linear(const vro_volume* v, const float p[3], float out[4])
 /* 3-D nearest (TFCalibrationApp.wgsl:172, samplerNN) */
 static void tex3_nearest(const vro_volume* v, const float p[3], float out[4])
 {
-    int i = clampi((int)floorf(p[0] * (float)v->nx), 0, v->nx - 1);
-    int j = clampi((int)floorf(p[1] * (float)v->ny), 0, v->ny - 1);
-    int k = clampi((int)floorf(p[2] * (float)v->nz), 0, v->nz - 1);
+    int i = clampi(f2i(floorf(p[0] * (float)v->nx)), 0, v->nx - 1);
+    int j = clampi(f2i(floorf(p[1] * (float)v->ny)), 0, v->ny - 1);
+    int k = clampi(f2i(floorf(p[2] * (float)v->nz)), 0, v->nz - 1);
     const float* t = v->vec4 + 4 * (((int64_t)k * v->ny + j) * v->nx + i);
     out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; out[3] = t[3];
 }
@@ -133,8 +151,7 @@ static void tf_coords(int res, float d, int* i0, int* i1, float* f)
     float x = d * (float)res - 0.5f;
     float x0 = floorf(x);
     *f = x - x0;
-    *i0 = clampi((int)x0, 0, res - 1);
-    *i1 = clampi((int)x0 + 1, 0, res - 1);
+    texel_pair(x0, res, i0, i1);
 }
 static float tf_opacity(const vro_tf* tf, float d) /* textureSample(tfOpacity, samplerLin, d).r */
 {

@@ -176,7 +176,7 @@ def zero_prefix_tf(res, zeros, top=0.3):
 def test_empty_space_skipping_is_exact(ctx, variant, zeros):
     """Skipped samples are exactly the identity: flavour 0 (skipping) == flavour 1 (plain) == oracle, bit for bit,
     for every length of the opacity table's zero prefix (incl. none, and all-zero)."""
-    W, H, n = 96, 64, 24
+    W, H, n = 96, 64, 40
     vols, tfs = vt.scene(variant, n=n)
     tfs[0] = zero_prefix_tf(64, zeros)
     step, count = hr.stepping_params(n, n, n)
@@ -193,15 +193,23 @@ def test_empty_space_skipping_is_exact(ctx, variant, zeros):
     if zeros == 0:
         assert fetched0 == comp0      # opacity[0] != 0: nothing may be skipped
     else:
-        assert fetched0 < comp0       # the phantom's air (density exactly 0) is skipped
-    if zeros >= 40:
-        assert fetched0 < 0.5 * comp0
+        assert fetched0 < comp0       # bricks of pure air (density exactly 0) are skipped
+    if zeros == 64:
+        assert fetched0 < 0.2 * comp0  # all-zero opacity table: only bricks holding near-maximal densities stay live
+
+
+def same(frag, ref):
+    """Bit-equal where finite; NaN where the oracle is NaN (NaN payload / sign bits are platform specific)."""
+    fin = np.isfinite(ref)
+    return (np.array_equal(vt.bits(frag)[fin], vt.bits(ref)[fin]) and np.array_equal(np.isnan(frag), np.isnan(ref))
+            and np.array_equal(frag[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)]))
 
 
 def test_skipping_with_hostile_values(ctx):
-    """NaN / inf / negative densities, non-finite colour tables and lights: skipping must either stay exact or
-    switch itself off."""
+    """NaN / inf / negative densities, non-finite colour tables and lights: no out-of-range access, and skipping
+    either stays exact or switches itself off."""
     W, H, n = 64, 48, 16
+    ctx.resize(W, H)
     rng = np.random.default_rng(3)
     v = np.zeros((n, n, n, 4), dtype=f32)
     v[4:12, 4:12, 4:12, 3] = rng.random((8, 8, 8), dtype=f32) * f32(0.5)
@@ -209,25 +217,30 @@ def test_skipping_with_hostile_values(ctx):
     v[2, 2, 2, 3] = -0.25
     v[13, 3, 3, 3] = np.inf
     v[3, 13, 13, 3] = np.nan
+    v[10, 13, 2, 3] = -np.inf
+    v[12, 2, 12, 3] = 3.0e38
     step, count = hr.stepping_params(n, n, n)
     u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
     tf = zero_prefix_tf(32, 3)
     for variant in (capi.BASIC, capi.LIGHT):
-        frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
-        ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
-        assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref
+        for flavour in (0, 1):
+            ctx.set_kernel_flavour(flavour)
+            frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
+            ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
+            assert same(frag, ref) and ns == n_ref, (variant, flavour)
+    ctx.set_kernel_flavour(0)
     # non-finite colour entry: 0 * inf = NaN would differ from a skipped sample -> skipping is disabled
     c = hr.default_color_tf(32).copy()
     c[0, 1] = np.inf
     frag, _, ns = vt.gpu_render(ctx, capi.BASIC, u, [v], [(tf[0], c)])
     ref, n_ref, _ = ob.render(capi.BASIC, u, [v], [(tf[0], c)], W, H, nthreads=8)
-    assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref
+    assert same(frag, ref) and ns == n_ref
     assert ctx.counters()[2] == ns
     # non-finite light
     u2 = hr.make_uniforms(W, H, steps_count=count, step_size=step, light_diffuse=(np.inf, 1.0, 1.0, 1.0))
     frag, _, ns = vt.gpu_render(ctx, capi.LIGHT, u2, [v], [tf])
     ref, n_ref, _ = ob.render(capi.LIGHT, u2, [v], [tf], W, H, nthreads=8)
-    assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref
+    assert same(frag, ref) and ns == n_ref
     assert ctx.counters()[2] == ns
 
 
@@ -237,6 +250,7 @@ def test_skipping_brick_boundaries(ctx):
     tf = zero_prefix_tf(64, 1, top=0.9)
     step, count = hr.stepping_params(n, n, n)
     u = hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=0.3, pitch=0.2)
+    ctx.resize(W, H)
     for pos in [(7, 7, 7), (8, 8, 8), (0, 0, 0), (23, 23, 23), (15, 16, 7), (8, 0, 23)]:
         v = np.zeros((n, n, n, 4), dtype=f32)
         v[pos[2], pos[1], pos[0], 3] = 1.0

@@ -39,6 +39,15 @@ __device__ __forceinline__ f3 normalize3(f3 a)
 __device__ __forceinline__ float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+// Texel pair of a clamp-to-edge linear fetch from the floored coordinate x0 (any float, incl. +-inf / NaN):
+// the f32 -> i32 conversion saturates (NaN -> 0, v_cvt_i32_f32), and the "+1" is applied after limiting the
+// value from above so that it can never overflow.  i0 = clamp(t, 0, n-1), i1 = clamp(t+1, 0, n-1).
+__device__ __forceinline__ void texel_pair(float x0, int n, int& i0, int& i1)
+{
+    int t = min((int)x0, n - 1);
+    i0 = max(t, 0);
+    i1 = min(max(t + 1, 0), n - 1);
+}
 
 // column-major mat4 * (x,y,z,1), summed left to right
 __device__ __forceinline__ void mat4_mul_point(const float* m, float x, float y, float z, float w, float out[4])
@@ -97,9 +106,10 @@ __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
     c.fx = x - x0;
     c.fy = y - y0;
     c.fz = z - z0;
-    int i0 = clampi((int)x0, 0, v.nx - 1), i1 = clampi((int)x0 + 1, 0, v.nx - 1);
-    int j0 = clampi((int)y0, 0, v.ny - 1), j1 = clampi((int)y0 + 1, 0, v.ny - 1);
-    int k0 = clampi((int)z0, 0, v.nz - 1), k1 = clampi((int)z0 + 1, 0, v.nz - 1);
+    int i0, i1, j0, j1, k0, k1;
+    texel_pair(x0, v.nx, i0, i1);
+    texel_pair(y0, v.ny, j0, j1);
+    texel_pair(z0, v.nz, k0, k1);
     unsigned r00 = ((unsigned)k0 * (unsigned)v.ny + (unsigned)j0) * (unsigned)v.nx;
     unsigned r10 = ((unsigned)k0 * (unsigned)v.ny + (unsigned)j1) * (unsigned)v.nx;
     unsigned r01 = ((unsigned)k1 * (unsigned)v.ny + (unsigned)j0) * (unsigned)v.nx;
@@ -194,11 +204,12 @@ __device__ __forceinline__ TfSample tf_lookup(const DevTF& tf, float d)
     float xo = d * (float)tf.res_o - 0.5f;
     float xo0 = floorf(xo);
     float fo = xo - xo0;
-    int o0i = clampi((int)xo0, 0, tf.res_o - 1), o1i = clampi((int)xo0 + 1, 0, tf.res_o - 1);
+    int o0i, o1i, c0i, c1i;
+    texel_pair(xo0, tf.res_o, o0i, o1i);
     float xc = d * (float)tf.res_c - 0.5f;
     float xc0 = floorf(xc);
     float fc = xc - xc0;
-    int c0i = clampi((int)xc0, 0, tf.res_c - 1), c1i = clampi((int)xc0 + 1, 0, tf.res_c - 1);
+    texel_pair(xc0, tf.res_c, c0i, c1i);
     float o0 = tf.opacity[o0i], o1 = tf.opacity[o1i];
     float4 c0 = tf.color[c0i], c1 = tf.color[c1i];
     TfSample s;
