@@ -225,7 +225,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     if (record_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
     VR_HIP(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), s));
     if (P.n_blocks > 0) {
-        dim3 grid((unsigned)((P.n_blocks + 7) / 8 * 8));
+        dim3 grid((unsigned)((P.n_tiles + 7) / 8 * 8 * kBlocksPerTile));  // whole tiles per XCD, see map_pixel
         const int slot = (int)(c->ring.head % kRing);
         if (record_events) {
             VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));

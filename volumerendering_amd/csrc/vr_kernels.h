@@ -389,16 +389,20 @@ struct PixelSlot {
     int px, py;      // screen pixel
     int out_index;   // where dst goes (frame index, or packed-tile index)
     bool active;     // inside the viewport and inside the launch
+    bool in_launch;  // the block's tile exists (the grid is padded to 8 x 16 blocks)
 };
 
 __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
 {
     PixelSlot s;
-    const int nb_pad = gridDim.x;  // multiple of 8
-    const int per_xcd = nb_pad >> 3;
-    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int n = lb / kBlocksPerTile;
-    const int sub = lb - n * kBlocksPerTile;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD; speed only, never
+    // correctness).  The 16 blocks of one 64x64 tile stay on ONE XCD (their rays traverse neighbouring voxels:
+    // shared L2 lines), while consecutive tiles go to different XCDs so that every XCD gets an even share of the
+    // heavy (volume-covered) and the empty parts of the screen.
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int n = xcd + 8 * (q / kBlocksPerTile);  // ordinal of the owned tile this block works on
+    const int sub = q % kBlocksPerTile;
+    const bool in_launch = n < P.n_tiles;
     const int t = P.rank + n * P.world;
     const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -407,7 +411,8 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
     const int tpx = ((sub & 3) << 4) + lx, tpy = ((sub >> 2) << 4) + ly;  // pixel inside the tile
     s.px = tx * kTile + tpx;
     s.py = ty * kTile + tpy;
-    s.active = (lb < P.n_blocks) && (s.px < P.W) && (s.py < P.H);
+    s.in_launch = in_launch;
+    s.active = in_launch && (s.px < P.W) && (s.py < P.H);
     s.out_index = P.packed ? (n * (kTile * kTile) + tpy * kTile + tpx) : (s.py * P.W + s.px);
     return s;
 }
@@ -512,9 +517,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
     }
 
     // packed-tile launches write every slot of an owned tile (pixels outside the viewport = 0)
-    const int nb_pad = gridDim.x;
-    const int lb = (blockIdx.x & 7) * (nb_pad >> 3) + (blockIdx.x >> 3);
-    if (slot.active || (P.packed && lb < P.n_blocks)) P.out[slot.out_index] = dst;
+    if (slot.active || (P.packed && slot.in_launch)) P.out[slot.out_index] = dst;
 
     // counters: wave reduction, one atomic pair per wave
     unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
