@@ -135,15 +135,23 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # VR_BENCH_DEVICE / VR_BENCH_BACKEND exist only to rehearse the N > 1 code path on a one-GPU box (all ranks on
+    # device 0, gloo through host memory); the real multi-GPU run uses one GPU per rank and RCCL.
+    device_index = int(os.environ.get("VR_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
 
     n, W, H, vname = WORKLOADS[args.workload]
-    app = host.Application(W, H, local_rank)
+    app = host.Application(W, H, device_index)
     variant, vols = build_scene(app, host, synth, capi, args.workload, args.tf, args.vol_n)
     ctx = app.context()
     if args.flavour:
@@ -164,7 +172,13 @@ def main():
             ctx.render_async(variant, frame.data_ptr(), stream)
         else:
             ctx.render_tiles_async(variant, rank, world, my_tiles.data_ptr(), stream)
-            dist.gather(my_tiles, gather_list, dst=0)  # RCCL over xGMI: every peer sends straight to the root
+            if backend == "nccl":
+                dist.gather(my_tiles, gather_list, dst=0)  # RCCL over xGMI: every peer sends straight to the root
+            else:  # rehearsal only: through host memory
+                host_list = [torch.empty(my_tiles.numel()) for _ in range(world)] if rank == 0 else None
+                dist.gather(my_tiles.cpu(), host_list, dst=0)
+                if rank == 0:
+                    gathered.copy_(torch.stack(host_list))
             if rank == 0:
                 ctx.unpack_tiles_async(gathered.data_ptr(), world, frame.data_ptr(), stream)
 
@@ -189,10 +203,10 @@ def main():
     ktimes = ctx.kernel_times(min(args.steps, 256))
     kernel_ms = float(np.mean(ktimes)) if len(ktimes) else float("nan")
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([my_samples, my_covered, my_fetched], dtype=torch.int64, device="cuda")
+        s = torch.tensor([my_samples, my_covered, my_fetched], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_samples, covered, total_fetched = int(s[0].item()), int(s[1].item()), int(s[2].item())
     else:
@@ -242,6 +256,13 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and os.environ.get("VR_BENCH_CHECK_FRAME"):
+        # rehearsal aid: the gathered frame must equal a single-rank render of the same scene, bit for bit
+        ctx.render_async(variant, 0, stream)
+        torch.cuda.synchronize()
+        ref, _, _ = ctx.download()
+        same = bool(np.array_equal(ref.view(np.uint32), frame.cpu().numpy().view(np.uint32)))
+        out["config"]["frame_equals_single_rank_render"] = same
     if rank == 0:
         print(json.dumps(out), flush=True)
     app.close()
