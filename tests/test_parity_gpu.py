@@ -171,7 +171,7 @@ def zero_prefix_tf(res, zeros, top=0.3):
     return o, hr.default_color_tf(res)
 
 
-@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.THREE_FILES])
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.VOLUME_MASK])
 @pytest.mark.parametrize("zeros", [0, 1, 2, 9, 17, 40, 64])
 def test_empty_space_skipping_is_exact(ctx, variant, zeros):
     """Skipped samples are exactly the identity: flavour 0 (skipping) == flavour 1 (plain) == oracle, bit for bit,
@@ -194,7 +194,7 @@ def test_empty_space_skipping_is_exact(ctx, variant, zeros):
         assert fetched0 == comp0      # opacity[0] != 0: nothing may be skipped
     else:
         assert fetched0 < comp0       # bricks of pure air (density exactly 0) are skipped
-    if zeros == 64:
+    if zeros == 64 and variant != capi.VOLUME_MASK:
         assert fetched0 < 0.2 * comp0  # all-zero opacity table: only bricks holding near-maximal densities stay live
 
 
@@ -259,3 +259,25 @@ def test_skipping_brick_boundaries(ctx):
         assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref, pos
         assert ref[..., 3].max() > 0
         assert ctx.counters()[2] < ns
+
+
+def test_volume_mask_skipping_respects_the_mask(ctx):
+    """Bricks where the mask can switch the sample to the RT table are never skipped, even over CT air."""
+    W, H, n = 96, 64, 40
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(capi.VOLUME_MASK, n=n)
+    mask = np.zeros((n, n, n, 4), dtype=f32)
+    mask[2:6, 2:6, 2:6, 1] = 1.0       # a blob in the corner of the box: CT is air there
+    mask[30:34, 8:12, 20:24, 2] = 0.5
+    vols[0] = mask
+    tfs[0] = zero_prefix_tf(64, 9)
+    tfs[1] = (np.full(128, 0.4, dtype=f32), tfs[1][1])   # RT table: opaque everywhere
+    step, count = hr.stepping_params(n, n, n)
+    for yaw in (0.6, 2.4, -1.0):
+        u = hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=yaw, pitch=0.4)
+        frag, ns = check(ctx, capi.VOLUME_MASK, u, vols, tfs, W, H)
+        assert ctx.counters()[2] < ns
+    # different grids for mask and CT: skipping must switch itself off, result unchanged
+    vols2 = [vt.hr.mask_vec4(24), vols[1], vols[2]]
+    frag, ns = check(ctx, capi.VOLUME_MASK, u, vols2, tfs, W, H)
+    assert ctx.counters()[2] == ns

@@ -35,6 +35,7 @@ struct vr_ctx {
     DevVolume vol[VR_MAX_VOLUMES] = {};
     size_t vol_bytes[VR_MAX_VOLUMES] = {};
     float* vol_brick_max[VR_MAX_VOLUMES] = {};  // per-brick max density (empty-space skipping)
+    float* vol_brick_rgb[VR_MAX_VOLUMES] = {};  // per-brick max(r,g,b)
     int tf_zero_prefix[VR_MAX_TFS] = {-1, -1};  // zero prefix of each opacity table, -1 if none / not finite
     bool tf_color_finite[VR_MAX_TFS] = {false, false};
     bool tf_opacity_finite[VR_MAX_TFS] = {false, false};
@@ -120,7 +121,7 @@ int alloc_frame(vr_ctx* c)
 template <int V>
 void launch_variant(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
 {
-    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES);
+    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
     if constexpr (kCanSkip) {
         if (P.brick_max) {
             if (off32)
@@ -195,14 +196,22 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     // exact empty-space skipping: only for the shaders whose opacity is the CT table value alone, only when a
     // zero-opacity sample is provably the identity (finite colour table and light), and unless flavour 1 asks
     // for the plain kernel
-    const bool skip_variant = variant == VR_VARIANT_BASIC || variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_THREE_FILES;
-    if (skip_variant && c->flavour != 1 && c->vol_brick_max[0] && c->tf_zero_prefix[0] >= 0 && c->tf_color_finite[0] &&
-        (variant != VR_VARIANT_THREE_FILES || (c->tf_color_finite[1] && c->tf_opacity_finite[1])) &&
-        all_finite(c->u.light_pos, 12)) {
-        P.brick_max = c->vol_brick_max[0];
-        P.bnx = (c->vol[0].nx + 7) >> kBrickShift;
-        P.bny = (c->vol[0].ny + 7) >> kBrickShift;
-        P.bnz = (c->vol[0].nz + 7) >> kBrickShift;
+    const bool skip_variant = variant == VR_VARIANT_BASIC || variant == VR_VARIANT_LIGHT ||
+                              variant == VR_VARIANT_THREE_FILES || variant == VR_VARIANT_VOLUME_MASK;
+    const int sv = (variant == VR_VARIANT_VOLUME_MASK) ? 2 : 0;  // the volume whose density drives tf[0]'s opacity
+    bool can_skip = skip_variant && c->flavour != 1 && c->vol_brick_max[sv] && c->tf_zero_prefix[0] >= 0 &&
+                    c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
+    if (variant == VR_VARIANT_THREE_FILES) can_skip = can_skip && c->tf_color_finite[1] && c->tf_opacity_finite[1];
+    if (variant == VR_VARIANT_VOLUME_MASK)  // mask and CT must share one grid so that one brick index serves both
+        can_skip = can_skip && c->vol_brick_rgb[0] && c->vol[0].nx == c->vol[2].nx && c->vol[0].ny == c->vol[2].ny &&
+                   c->vol[0].nz == c->vol[2].nz;
+    if (can_skip) {
+        P.brick_max = c->vol_brick_max[sv];
+        P.brick_rgb = (variant == VR_VARIANT_VOLUME_MASK) ? c->vol_brick_rgb[0] : nullptr;
+        P.skip_vol = sv;
+        P.bnx = (c->vol[sv].nx + 7) >> kBrickShift;
+        P.bny = (c->vol[sv].ny + 7) >> kBrickShift;
+        P.bnz = (c->vol[sv].nz + 7) >> kBrickShift;
         P.tf_zero_prefix = c->tf_zero_prefix[0];
     }
 
@@ -334,6 +343,8 @@ void vr_destroy(vr_ctx* c)
         if (c->vol[i].data) (void)hipFree(const_cast<float4*>(c->vol[i].data));
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
         if (c->vol_brick_max[i]) (void)hipFree(c->vol_brick_max[i]);
+    for (int i = 0; i < VR_MAX_VOLUMES; ++i)
+        if (c->vol_brick_rgb[i]) (void)hipFree(c->vol_brick_rgb[i]);
     for (int i = 0; i < VR_MAX_TFS; ++i) {
         if (c->tf_opacity[i]) (void)hipFree(c->tf_opacity[i]);
         if (c->tf_color[i]) (void)hipFree(c->tf_color[i]);
@@ -387,12 +398,15 @@ static int volume_upload_common(vr_ctx* c, int slot, const void* src, bool src_i
     c->vol_bytes[slot] = bytes;
     // per-brick density maxima for the exact empty-space test (one pass over the volume, at upload time)
     if (c->vol_brick_max[slot]) (void)hipFree(c->vol_brick_max[slot]);
+    if (c->vol_brick_rgb[slot]) (void)hipFree(c->vol_brick_rgb[slot]);
     c->vol_brick_max[slot] = nullptr;
+    c->vol_brick_rgb[slot] = nullptr;
     const int bnx = (nx + 7) >> kBrickShift, bny = (ny + 7) >> kBrickShift, bnz = (nz + 7) >> kBrickShift;
     const size_t nbricks = (size_t)bnx * bny * bnz;
     VR_HIP(c, hipMalloc(&c->vol_brick_max[slot], nbricks * sizeof(float)));
+    VR_HIP(c, hipMalloc(&c->vol_brick_rgb[slot], nbricks * sizeof(float)));
     hipLaunchKernelGGL(brick_max_kernel, dim3((unsigned)nbricks), dim3(64), 0, c->stream, d, (int)nx, (int)ny, (int)nz, bnx,
-                       bny, c->vol_brick_max[slot]);
+                       bny, c->vol_brick_max[slot], c->vol_brick_rgb[slot]);
     VR_HIP(c, hipGetLastError());
     VR_HIP(c, hipStreamSynchronize(c->stream));
     return VR_OK;

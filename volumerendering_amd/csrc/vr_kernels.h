@@ -425,7 +425,7 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
 // bm <= 0 (all-zero / negative cells) only ever addresses opacity[0].  NaN bm fails every comparison -> active.
 __device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
 {
-    const DevVolume& v = P.vol[0];
+    const DevVolume& v = P.vol[P.skip_vol];
     int i0 = clampi((int)floorf(p.x * (float)v.nx - 0.5f), 0, v.nx - 1);
     int j0 = clampi((int)floorf(p.y * (float)v.ny - 0.5f), 0, v.ny - 1);
     int k0 = clampi((int)floorf(p.z * (float)v.nz - 0.5f), 0, v.nz - 1);
@@ -434,6 +434,9 @@ __device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
 __device__ __forceinline__ bool brick_inert(const MarchParams& P, int bid)
 {
     float bm = P.brick_max[bid];
+    // VOLUME_MASK: a mask sample with r, g or b > 0 switches to the RT table; if every mask voxel the brick can touch
+    // has max(r,g,b) <= 0 the interpolated channels are <= 0 too, so the CT opacity is the one that is blended
+    if (P.brick_rgb && !(P.brick_rgb[bid] <= 0.0f)) return false;
     if (bm <= 0.0f) return P.tf_zero_prefix >= 0;
     return floorf(bm * (float)P.tf[0].res_o - 0.5f) + 2.0f <= (float)P.tf_zero_prefix;
 }
@@ -535,26 +538,33 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
 
 // One wavefront per brick: maximum of .a over the voxels [8b, min(8b+8, n-1)]^3 (NaN if any voxel is NaN).
 __global__ __launch_bounds__(64) void brick_max_kernel(const float4* __restrict__ vol, int nx, int ny, int nz, int bnx,
-                                                       int bny, float* __restrict__ out)
+                                                       int bny, float* __restrict__ out, float* __restrict__ out_rgb)
 {
     const int b = blockIdx.x;
     const int bx = b % bnx, by = (b / bnx) % bny, bz = b / (bnx * bny);
     const int x0 = bx << kBrickShift, y0 = by << kBrickShift, z0 = bz << kBrickShift;
     const int ex = min(9, nx - x0), ey = min(9, ny - y0), ez = min(9, nz - z0);
-    float m = -INFINITY;
-    bool has_nan = false;
+    float m = -INFINITY, mc = -INFINITY;
+    bool has_nan = false, has_nan_c = false;
     for (int t = threadIdx.x; t < ex * ey * ez; t += 64) {
         int lx = t % ex, ly = (t / ex) % ey, lz = t / (ex * ey);
-        float a = vol[((size_t)(z0 + lz) * ny + (y0 + ly)) * nx + (x0 + lx)].w;
-        if (a != a) has_nan = true;
-        else if (a > m) m = a;
+        float4 v = vol[((size_t)(z0 + lz) * ny + (y0 + ly)) * nx + (x0 + lx)];
+        if (v.w != v.w) has_nan = true;
+        else if (v.w > m) m = v.w;
+        if (v.x != v.x || v.y != v.y || v.z != v.z) has_nan_c = true;
+        else mc = fmaxf(mc, fmaxf(v.x, fmaxf(v.y, v.z)));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         m = fmaxf(m, __shfl_down(m, off, 64));
+        mc = fmaxf(mc, __shfl_down(mc, off, 64));
         has_nan = has_nan || (__shfl_down((int)has_nan, off, 64) != 0);
+        has_nan_c = has_nan_c || (__shfl_down((int)has_nan_c, off, 64) != 0);
     }
-    if (threadIdx.x == 0) out[b] = has_nan ? NAN : m;
+    if (threadIdx.x == 0) {
+        out[b] = has_nan ? NAN : m;
+        out_rgb[b] = has_nan_c ? NAN : mc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ aux kernels
