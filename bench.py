@@ -163,24 +163,44 @@ def main():
     tile_floats = capi.TILE * capi.TILE * 4
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     if world > 1:
-        my_tiles = torch.zeros((tpr_max * tile_floats,), dtype=torch.float32, device="cuda")
-        gathered = torch.zeros((world, tpr_max * tile_floats), dtype=torch.float32, device="cuda") if rank == 0 else None
-        gather_list = [gathered[r] for r in range(world)] if rank == 0 else None
+        # two tile buffers: the gather of frame k overlaps the render of frame k+1 (one frame of latency, as any
+        # pipelined renderer has); every frame's gather and un-permute completes inside the timed region
+        my_tiles = [torch.zeros((tpr_max * tile_floats,), dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.zeros((world, tpr_max * tile_floats), dtype=torch.float32, device="cuda") for _ in range(2)] \
+            if rank == 0 else [None, None]
+        gather_list = [[g[r] for r in range(world)] for g in gathered] if rank == 0 else [None, None]
 
-    def one_frame():
+    def run_frames(n_frames):
         if world == 1:
-            ctx.render_async(variant, frame.data_ptr(), stream)
-        else:
-            ctx.render_tiles_async(variant, rank, world, my_tiles.data_ptr(), stream)
+            for _ in range(n_frames):
+                ctx.render_async(variant, frame.data_ptr(), stream)
+            return
+        pending = None  # (work handle, buffer index) of the previous frame's gather
+        for k in range(n_frames):
+            b = k & 1
+            ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), stream)
             if backend == "nccl":
-                dist.gather(my_tiles, gather_list, dst=0)  # RCCL over xGMI: every peer sends straight to the root
-            else:  # rehearsal only: through host memory
-                host_list = [torch.empty(my_tiles.numel()) for _ in range(world)] if rank == 0 else None
-                dist.gather(my_tiles.cpu(), host_list, dst=0)
+                # RCCL over xGMI: every peer sends straight to the root (7 links in parallel, not a ring)
+                work = dist.gather(my_tiles[b], gather_list[b], dst=0, async_op=True)
+            else:  # rehearsal only: through host memory, synchronous
+                host_list = [torch.empty(my_tiles[b].numel()) for _ in range(world)] if rank == 0 else None
+                dist.gather(my_tiles[b].cpu(), host_list, dst=0)
                 if rank == 0:
-                    gathered.copy_(torch.stack(host_list))
+                    gathered[b].copy_(torch.stack(host_list))
+                work = None
+            if pending is not None:
+                pw, pb = pending
+                if pw is not None:
+                    pw.wait()  # orders the current stream after that gather (no host block)
+                if rank == 0:
+                    ctx.unpack_tiles_async(gathered[pb].data_ptr(), world, frame.data_ptr(), stream)
+            pending = (work, b)
+        if pending is not None:
+            pw, pb = pending
+            if pw is not None:
+                pw.wait()
             if rank == 0:
-                ctx.unpack_tiles_async(gathered.data_ptr(), world, frame.data_ptr(), stream)
+                ctx.unpack_tiles_async(gathered[pb].data_ptr(), world, frame.data_ptr(), stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -188,13 +208,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_frame()
+    run_frames(args.warmup)
     sync_all()
     ctx.reset_kernel_times()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_frame()
+    run_frames(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
 
@@ -240,7 +258,8 @@ def main():
         "config": {
             "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, "
                         f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
-            "partition": "single GPU" if world == 1 else f"64x64 image tiles interleaved over {world} GPUs + RCCL gather",
+            "partition": "single GPU" if world == 1 else
+                         f"64x64 image tiles interleaved over {world} GPUs + RCCL gather (pipelined one frame deep)",
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
             "covered_pixels": covered, "kernel_flavour": args.flavour,
         },
