@@ -123,6 +123,25 @@ int vr_volume_upload(vr_ctx* ctx, int slot, const float* vec4_voxels, uint16_t n
 /* Same, from a DEVICE pointer that already holds the vec4 voxels (no host round trip). */
 int vr_volume_upload_device(vr_ctx* ctx, int slot, const void* d_vec4_voxels, uint16_t nx, uint16_t ny, uint16_t nz);
 
+/* ---- data preparation on the device ------------------------------------------------------
+ * The reference prepares volumes on one CPU thread at load time; these do the same arithmetic on the GPU,
+ * in place on an uploaded slot, bit for bit (tests/test_prep_gpu.py).
+ *
+ * vr_volume_upload_raw16/32: the readers' broadcast of the raw integer to all four lanes
+ *   (App/src/file/dicom/DicomReader.cpp:239,247; App/src/file/dat/DatReader.cpp:42).
+ * vr_volume_normalize: VolumeFile::NormalizeData (App/src/file/VolumeFile.cpp:165-184): .a /= value;
+ *   value == 0 -> the maximum of component [0] truncated to an integer (GetMaxNumber, :53-60); the value used is
+ *   returned through *used_value (may be NULL).
+ * vr_volume_precompute_gradient: VolumeFile::PreComputeGradient (VolumeFile.cpp:196-257): .rgb = (-(p - m)) * 0.5
+ *   per axis from the +-1 neighbours' .a (0 outside the grid); norm_to_zero_one != 0 divides every component by
+ *   the largest gradient magnitude.
+ * vr_volume_download: reads a slot back (n voxels * 4 floats).                                               */
+int vr_volume_upload_raw16(vr_ctx* ctx, int slot, const uint16_t* raw, uint16_t nx, uint16_t ny, uint16_t nz);
+int vr_volume_upload_raw32(vr_ctx* ctx, int slot, const uint32_t* raw, uint16_t nx, uint16_t ny, uint16_t nz);
+int vr_volume_normalize(vr_ctx* ctx, int slot, int normalization_value, int* used_value);
+int vr_volume_precompute_gradient(vr_ctx* ctx, int slot, int norm_to_zero_one);
+int vr_volume_download(vr_ctx* ctx, int slot, float* vec4_voxels);
+
 /* Replaces: OpacityTF / ColorTF texture creation and TransferFunction::UpdateTexture
  * (App/src/tf/OpacityTf.cpp:25-26,134-142; App/src/tf/ColorTf.cpp:23-24).  opacity: R floats
  * (R32Float 1-D), color_rgba: 4R floats (RGBA32Float 1-D).                                       */

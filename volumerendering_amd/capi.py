@@ -27,7 +27,8 @@ TILE = 64
 # every symbol include/vr.h declares (tests check that the library exports each of them)
 ABI_SYMBOLS = [
     "vr_create", "vr_resize", "vr_destroy", "vr_last_error", "vr_abi_version", "vr_volume_upload",
-    "vr_volume_upload_device", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
+    "vr_volume_upload_device", "vr_volume_upload_raw16", "vr_volume_upload_raw32", "vr_volume_normalize",
+    "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour",
 ]
@@ -76,6 +77,11 @@ def load() -> C.CDLL:
     lib.vr_abi_version.argtypes = []
     lib.vr_volume_upload.argtypes = [vp, i32, vp, u16, u16, u16]
     lib.vr_volume_upload_device.argtypes = [vp, i32, vp, u16, u16, u16]
+    lib.vr_volume_upload_raw16.argtypes = [vp, i32, vp, u16, u16, u16]
+    lib.vr_volume_upload_raw32.argtypes = [vp, i32, vp, u16, u16, u16]
+    lib.vr_volume_normalize.argtypes = [vp, i32, i32, C.POINTER(C.c_int)]
+    lib.vr_volume_precompute_gradient.argtypes = [vp, i32, i32]
+    lib.vr_volume_download.argtypes = [vp, i32, vp]
     lib.vr_tf_upload.argtypes = [vp, i32, vp, vp, u32]
     lib.vr_tf_upload_opacity.argtypes = [vp, i32, vp, u32]
     lib.vr_tf_upload_color.argtypes = [vp, i32, vp, u32]
@@ -151,6 +157,28 @@ class Context:
 
     def volume_upload_device(self, slot: int, dptr: int, nx: int, ny: int, nz: int):
         self._chk(self.lib.vr_volume_upload_device(self.h, slot, dptr, nx, ny, nz))
+
+    def volume_upload_raw(self, slot: int, raw: np.ndarray):
+        """raw: uint16 or uint32 array (nz, ny, nx); broadcast to vec4 on the device."""
+        raw = np.ascontiguousarray(raw)
+        nz, ny, nx = raw.shape
+        fn = {np.dtype(np.uint16): self.lib.vr_volume_upload_raw16, np.dtype(np.uint32): self.lib.vr_volume_upload_raw32}[raw.dtype]
+        self._chk(fn(self.h, slot, raw.ctypes.data, nx, ny, nz))
+        self._shapes = getattr(self, "_shapes", {})
+        self._shapes[slot] = (nz, ny, nx)
+
+    def volume_normalize(self, slot: int, value: int = 0) -> int:
+        used = C.c_int(0)
+        self._chk(self.lib.vr_volume_normalize(self.h, slot, value, C.byref(used)))
+        return int(used.value)
+
+    def volume_precompute_gradient(self, slot: int, norm_to_zero_one: bool = False):
+        self._chk(self.lib.vr_volume_precompute_gradient(self.h, slot, int(norm_to_zero_one)))
+
+    def volume_download(self, slot: int, shape) -> np.ndarray:
+        out = np.empty(tuple(shape) + (4,), dtype=np.float32)
+        self._chk(self.lib.vr_volume_download(self.h, slot, out.ctypes.data))
+        return out
 
     def tf_upload(self, slot: int, opacity: np.ndarray, color_rgba: np.ndarray):
         o, c = _f32(opacity), _f32(color_rgba)

@@ -74,6 +74,8 @@ int fail(vr_ctx* c, int code, const std::string& msg)
                         std::string(#call) + ": " + hipGetErrorString(e__));                          \
     } while (0)
 
+int refresh_bricks(vr_ctx* c, int slot);
+
 int tiles_x_of(const vr_ctx* c) { return (int)((c->W + kTile - 1) / kTile); }
 int tiles_y_of(const vr_ctx* c) { return (int)((c->H + kTile - 1) / kTile); }
 
@@ -266,9 +268,140 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     return VR_OK;
 }
 
+// per-brick density / rgb maxima for the exact empty-space test (one pass over the volume; after every change)
+int refresh_bricks(vr_ctx* c, int slot)
+{
+    const DevVolume& v = c->vol[slot];
+    if (c->vol_brick_max[slot]) (void)hipFree(c->vol_brick_max[slot]);
+    if (c->vol_brick_rgb[slot]) (void)hipFree(c->vol_brick_rgb[slot]);
+    c->vol_brick_max[slot] = nullptr;
+    c->vol_brick_rgb[slot] = nullptr;
+    const int bnx = (v.nx + 7) >> kBrickShift, bny = (v.ny + 7) >> kBrickShift, bnz = (v.nz + 7) >> kBrickShift;
+    const size_t nbricks = (size_t)bnx * bny * bnz;
+    VR_HIP(c, hipMalloc(&c->vol_brick_max[slot], nbricks * sizeof(float)));
+    VR_HIP(c, hipMalloc(&c->vol_brick_rgb[slot], nbricks * sizeof(float)));
+    hipLaunchKernelGGL(brick_max_kernel, dim3((unsigned)nbricks), dim3(64), 0, c->stream, v.data, v.nx, v.ny, v.nz, bnx, bny,
+                       c->vol_brick_max[slot], c->vol_brick_rgb[slot]);
+    VR_HIP(c, hipGetLastError());
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    return VR_OK;
+}
+
+int check_slot(vr_ctx* c, int slot, const char* who)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= VR_MAX_VOLUMES) return fail(c, VR_ERR_INVALID_ARG, std::string(who) + ": bad slot");
+    if (!c->vol[slot].data) return fail(c, VR_ERR_NOT_READY, std::string(who) + ": volume slot is empty");
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    return VR_OK;
+}
+
+template <typename T>
+int upload_raw(vr_ctx* c, int slot, const T* raw, uint16_t nx, uint16_t ny, uint16_t nz)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= VR_MAX_VOLUMES) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload_raw: bad slot");
+    if (!raw) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload_raw: data is NULL");
+    if (nx == 0 || ny == 0 || nz == 0) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload_raw: empty volume");
+    const size_t n = (size_t)nx * ny * nz;
+    if (n > 0xFFFFFFFFull) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload_raw: more than 2^32 voxels");
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t bytes = n * sizeof(float4);
+    if (c->vol[slot].data && c->vol_bytes[slot] != bytes) {
+        (void)hipFree(const_cast<float4*>(c->vol[slot].data));
+        c->vol[slot] = DevVolume{};
+        c->vol_bytes[slot] = 0;
+    }
+    float4* d = const_cast<float4*>(c->vol[slot].data);
+    if (!d) VR_HIP(c, hipMalloc(&d, bytes));
+    T* d_raw = nullptr;
+    hipError_t e = hipMalloc(&d_raw, n * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_raw, raw, n * sizeof(T), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((broadcast_raw_kernel<T>), dim3(2048), dim3(256), 0, c->stream, d_raw, d, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_raw) (void)hipFree(d_raw);
+    if (e != hipSuccess) {
+        if (!c->vol[slot].data) (void)hipFree(d);
+        return fail(c, e == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_HIP,
+                    std::string("vr_volume_upload_raw: ") + hipGetErrorString(e));
+    }
+    c->vol[slot].data = d;
+    c->vol[slot].nx = nx;
+    c->vol[slot].ny = ny;
+    c->vol[slot].nz = nz;
+    c->vol_bytes[slot] = bytes;
+    return refresh_bricks(c, slot);
+}
+
 }  // namespace
 
 extern "C" {
+
+int vr_volume_upload_raw16(vr_ctx* c, int slot, const uint16_t* raw, uint16_t nx, uint16_t ny, uint16_t nz)
+{
+    return upload_raw(c, slot, raw, nx, ny, nz);
+}
+int vr_volume_upload_raw32(vr_ctx* c, int slot, const uint32_t* raw, uint16_t nx, uint16_t ny, uint16_t nz)
+{
+    return upload_raw(c, slot, raw, nx, ny, nz);
+}
+
+int vr_volume_normalize(vr_ctx* c, int slot, int normalization_value, int* used_value)
+{
+    int rc = check_slot(c, slot, "vr_volume_normalize");
+    if (rc != VR_OK) return rc;
+    float4* d = const_cast<float4*>(c->vol[slot].data);
+    const size_t n = (size_t)c->vol[slot].nx * c->vol[slot].ny * c->vol[slot].nz;
+    if (normalization_value == 0) {  // GetMaxNumber(): max of component [0], truncated
+        unsigned* d_max = reinterpret_cast<unsigned*>(c->d_counters);
+        VR_HIP(c, hipMemsetAsync(d_max, 0, sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(max_component_kernel, dim3(2048), dim3(256), 0, c->stream, d, n, 0, d_max);
+        VR_HIP(c, hipGetLastError());
+        unsigned bits = 0;
+        VR_HIP(c, hipMemcpyAsync(&bits, d_max, sizeof bits, hipMemcpyDeviceToHost, c->stream));
+        VR_HIP(c, hipStreamSynchronize(c->stream));
+        float mx;
+        std::memcpy(&mx, &bits, sizeof mx);
+        normalization_value = (int)(size_t)mx;
+    }
+    if (used_value) *used_value = normalization_value;
+    hipLaunchKernelGGL(normalize_kernel, dim3(2048), dim3(256), 0, c->stream, d, n, normalization_value);
+    VR_HIP(c, hipGetLastError());
+    return refresh_bricks(c, slot);
+}
+
+int vr_volume_precompute_gradient(vr_ctx* c, int slot, int norm_to_zero_one)
+{
+    int rc = check_slot(c, slot, "vr_volume_precompute_gradient");
+    if (rc != VR_OK) return rc;
+    float4* d = const_cast<float4*>(c->vol[slot].data);
+    const DevVolume& v = c->vol[slot];
+    const size_t n = (size_t)v.nx * v.ny * v.nz;
+    unsigned* d_max = reinterpret_cast<unsigned*>(c->d_counters);
+    VR_HIP(c, hipMemsetAsync(d_max, 0, sizeof(unsigned), c->stream));
+    dim3 block(256), grid((unsigned)((v.nx + 255) / 256), (unsigned)v.ny, (unsigned)v.nz);
+    hipLaunchKernelGGL(gradient_kernel, grid, block, 0, c->stream, d, v.nx, v.ny, v.nz, norm_to_zero_one ? 1 : 0, d_max);
+    VR_HIP(c, hipGetLastError());
+    if (norm_to_zero_one) {
+        hipLaunchKernelGGL(scale_gradient_kernel, dim3(2048), dim3(256), 0, c->stream, d, n, d_max);
+        VR_HIP(c, hipGetLastError());
+    }
+    return refresh_bricks(c, slot);
+}
+
+int vr_volume_download(vr_ctx* c, int slot, float* vec4_voxels)
+{
+    int rc = check_slot(c, slot, "vr_volume_download");
+    if (rc != VR_OK) return rc;
+    if (!vec4_voxels) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_download: destination is NULL");
+    VR_HIP(c, hipMemcpy(vec4_voxels, c->vol[slot].data, c->vol_bytes[slot], hipMemcpyDeviceToHost));
+    return VR_OK;
+}
 
 int vr_abi_version(void) { return VR_ABI_VERSION; }
 
@@ -396,20 +529,7 @@ static int volume_upload_common(vr_ctx* c, int slot, const void* src, bool src_i
     c->vol[slot].ny = ny;
     c->vol[slot].nz = nz;
     c->vol_bytes[slot] = bytes;
-    // per-brick density maxima for the exact empty-space test (one pass over the volume, at upload time)
-    if (c->vol_brick_max[slot]) (void)hipFree(c->vol_brick_max[slot]);
-    if (c->vol_brick_rgb[slot]) (void)hipFree(c->vol_brick_rgb[slot]);
-    c->vol_brick_max[slot] = nullptr;
-    c->vol_brick_rgb[slot] = nullptr;
-    const int bnx = (nx + 7) >> kBrickShift, bny = (ny + 7) >> kBrickShift, bnz = (nz + 7) >> kBrickShift;
-    const size_t nbricks = (size_t)bnx * bny * bnz;
-    VR_HIP(c, hipMalloc(&c->vol_brick_max[slot], nbricks * sizeof(float)));
-    VR_HIP(c, hipMalloc(&c->vol_brick_rgb[slot], nbricks * sizeof(float)));
-    hipLaunchKernelGGL(brick_max_kernel, dim3((unsigned)nbricks), dim3(64), 0, c->stream, d, (int)nx, (int)ny, (int)nz, bnx,
-                       bny, c->vol_brick_max[slot], c->vol_brick_rgb[slot]);
-    VR_HIP(c, hipGetLastError());
-    VR_HIP(c, hipStreamSynchronize(c->stream));
-    return VR_OK;
+    return refresh_bricks(c, slot);
 }
 
 int vr_volume_upload(vr_ctx* c, int slot, const float* vec4_voxels, uint16_t nx, uint16_t ny, uint16_t nz)

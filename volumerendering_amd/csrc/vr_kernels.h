@@ -602,4 +602,89 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4*
     frame[(size_t)y * W + x] = gathered[src];
 }
 
+// ------------------------------------------------------------------------------------------------ data preparation
+//  the reference's single-threaded CPU passes over the voxels, as HBM-bound streaming kernels.
+
+template <typename T>
+__global__ void broadcast_raw_kernel(const T* __restrict__ raw, float4* __restrict__ vol, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = (float)raw[i];
+        vol[i] = make_float4(v, v, v, v);
+    }
+}
+
+// out[0] = max over voxels of component `comp` (as f32 bits; values are >= 0 in every use: raw data, magnitudes)
+__global__ void max_component_kernel(const float4* __restrict__ vol, size_t n, int comp, unsigned* __restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float m = 0.0f;
+    for (; i < n; i += stride) {
+        float4 v = vol[i];
+        float c = comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w));
+        if (m < c) m = c;  // std::max_element semantics of GetMaxNumber: NaNs never win
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bits
+}
+
+__global__ void normalize_kernel(float4* __restrict__ vol, size_t n, int value)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float d = (float)value;
+    for (; i < n; i += stride) {
+        float4 v = vol[i];
+        v.w = v.w / d;
+        vol[i] = v;
+    }
+}
+
+// One thread per voxel, x fastest (coalesced); the density is read from the untouched .w lanes, so the pass can
+// run in place.  max_mag (f32 bits) accumulates the largest |gradient| when requested.
+__global__ void gradient_kernel(float4* __restrict__ vol, int nx, int ny, int nz, int want_max, unsigned* __restrict__ max_mag)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, z = blockIdx.z;
+    float mag = 0.0f;
+    if (x < nx) {
+        const size_t row = ((size_t)z * ny + y) * nx;
+        const size_t c = row + x;
+        const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+        float mx = x > 0 ? vol[c - 1].w : 0.0f, px = x + 1 < nx ? vol[c + 1].w : 0.0f;
+        float my = y > 0 ? vol[c - sy].w : 0.0f, py = y + 1 < ny ? vol[c + sy].w : 0.0f;
+        float mz = z > 0 ? vol[c - sz].w : 0.0f, pz = z + 1 < nz ? vol[c + sz].w : 0.0f;
+        float tx = (-(px - mx)) * 0.5f, ty = (-(py - my)) * 0.5f, tz = (-(pz - mz)) * 0.5f;
+        if (want_max) mag = sqrtf((tx * tx + ty * ty) + tz * tz);
+        float* o = reinterpret_cast<float*>(vol + c);
+        o[0] = tx;
+        o[1] = ty;
+        o[2] = tz;
+    }
+    if (want_max) {
+        if (!(mag > 0.0f)) mag = 0.0f;  // `if (mag > maxGradMag)`: NaN never wins
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mag = fmaxf(mag, __shfl_down(mag, off, 64));
+        if ((threadIdx.x & 63) == 0 && mag > 0.0f) atomicMax(max_mag, __float_as_uint(mag));
+    }
+}
+
+__global__ void scale_gradient_kernel(float4* __restrict__ vol, size_t n, const unsigned* __restrict__ max_mag)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float d = __uint_as_float(*max_mag);
+    for (; i < n; i += stride) {
+        float4 v = vol[i];
+        v.x = v.x / d;
+        v.y = v.y / d;
+        v.z = v.z / d;
+        vol[i] = v;
+    }
+}
+
 }  // namespace vr
