@@ -97,3 +97,18 @@ def test_differing_tf_resolutions_in_one_pair():
         frag, _, ns = vt.gpu_render(ctx, capi.LIGHT, u, vols, [tf])
     ref, n_ref, _ = ob.render(ob.LIGHT, u, vols, [tf], W, H, nthreads=8)
     assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref
+
+
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT])
+def test_scene_prepared_on_device_equals_host_prepared(variant):
+    """MiniApp::SetPrepareOnDevice: NormalizeData / PreComputeGradient run as GPU kernels; same frame."""
+    W, H, n = 96, 64, 24
+    frames = []
+    for on_device in (False, True):
+        with host.Application(W, H, 0) as app:
+            app.OnStart(variant, [host.VolumeFile.from_raw(synth.ct_phantom_raw(n))], prepare_on_device=on_device)
+            app.camera().SetOrbit(0.35, 0.6, 1.2)
+            app.OnUpdate(); app.OnRender()
+            frag, _, ns = app.ReadFrame()
+            frames.append((frag, ns))
+    assert np.array_equal(vt.bits(frames[0][0]), vt.bits(frames[1][0])) and frames[0][1] == frames[1][1] > 0

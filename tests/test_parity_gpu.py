@@ -281,3 +281,30 @@ def test_volume_mask_skipping_respects_the_mask(ctx):
     vols2 = [vt.hr.mask_vec4(24), vols[1], vols[2]]
     frag, ns = check(ctx, capi.VOLUME_MASK, u, vols2, tfs, W, H)
     assert ctx.counters()[2] == ns
+
+
+@pytest.mark.parametrize("flavour", [2, 3])
+def test_lds_wave_tile_flavours_are_exact(ctx, flavour):
+    """Flavours 2 / 3 stage the voxels of the lit shader through LDS wave tiles: same frame, same counts."""
+    cases = [
+        (96, 80, 24, dict(yaw=0.6, pitch=0.35)),
+        (130, 70, 40, dict(yaw=2.5, pitch=-1.0, distance=0.8)),
+        (64, 48, 16, dict(yaw=0.0, pitch=0.0, distance=5.0)),
+        (65, 33, 32, dict(yaw=-0.9, pitch=1.2, distance=0.75)),
+    ]
+    try:
+        for (W, H, n, cam) in cases:
+            vols, tfs = vt.scene(capi.LIGHT, n=n)
+            step, count = hr.stepping_params(n, n, n)
+            for extra in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.1, 0.0)), dict(toggles=(1, 1, 0, 0))):
+                u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam, **extra)
+                ctx.set_kernel_flavour(flavour)
+                check(ctx, capi.LIGHT, u, vols, tfs, W, H)
+        # anisotropic grid + a box too large for the tile at grazing distance (falls back per pair of steps)
+        raw = hr.ct_phantom_raw(24)[:10, :17, :]
+        v = ob.precompute_gradient(ob.normalize_data(hr.raw_to_vec4(raw)))
+        tf = (hr.default_opacity_tf(32), hr.default_color_tf(32))
+        u = hr.make_uniforms(64, 48, steps_count=41, step_size=1 / 24, distance=0.62, yaw=0.1, pitch=0.05)
+        check(ctx, capi.LIGHT, u, [v], [tf], 64, 48)
+    finally:
+        ctx.set_kernel_flavour(0)

@@ -25,6 +25,7 @@ void Application::OnStart(std::unique_ptr<MiniApp> app)
 {
     p_App = std::move(app);
     if (!p_Ctx || !p_App) return;
+    p_App->SetPrepareOnDevice(m_PrepareOnDevice);
     p_App->OnStart(p_Ctx);
     // "Using MiniApp's required step size / count" (Application.cpp:74-84)
     if (p_App->GetStepSize() != 0.0f) m_StepSize = p_App->GetStepSize();

@@ -41,6 +41,7 @@ public:
     float m_StepSize = 0.01f;
     vrm::vec2 m_ClipsX{}, m_ClipsY{}, m_ClipsZ{};
     bool m_BToggles[4] = {false, false, false, false};  // (variable step size, jitter, -, -)
+    bool m_PrepareOnDevice = false;  // forwarded to the scene in OnStart (MiniApp::SetPrepareOnDevice)
 
     // read back the fragment output / the presented BGRA8 frame of the last OnRender
     int ReadFrame(float* frag_rgba, uint8_t* present_bgra8 = nullptr, uint64_t* samples = nullptr);

@@ -32,6 +32,10 @@ public:
         // the longest ray through a unit cube is sqrt(3): with step 1/max that many steps cover it
         m_StepsCount = static_cast<int>(std::sqrt(3) * max);
     }
+    // Data preparation on the GPU instead of the reference's single-threaded CPU loops (same arithmetic, bit for
+    // bit): the scene uploads the un-prepared voxels and runs vr_volume_normalize / vr_volume_precompute_gradient
+    // in the order its OnStart uses.  The host VolumeFile is left as loaded.
+    void SetPrepareOnDevice(bool on) { m_PrepareOnDevice = on; }
     float GetStepSize() const { return m_StepSize; }
     int GetStepsCount() const { return m_StepsCount; }
     std::tuple<float, float, float> GetBBoxSize() const { return m_BBoxSize; }
@@ -42,6 +46,7 @@ protected:
         auto [x, y, z] = f.GetSize();
         vr_volume_upload(ctx, slot, static_cast<const float*>(f.GetVoidPtr()), x, y, z);
     }
+    bool m_PrepareOnDevice = false;
     float m_StepSize = 0.0f;
     int m_StepsCount = 0;
     std::tuple<float, float, float> m_BBoxSize = {0.0f, 0.0f, 0.0f};

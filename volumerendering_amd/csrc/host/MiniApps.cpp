@@ -6,12 +6,18 @@ namespace med {
 // ---- BasicVolumeApp::DemoBasic (App/src/miniapps/BasicVolumeApp.cpp:74-93) -------------------------------------
 void BasicVolumeApp::OnStart(vr_ctx* ctx)
 {
-    p_Ct->NormalizeData();
+    const bool onDevice = m_PrepareOnDevice && !p_Ct->IsNormalized();
+    if (onDevice) {
+        Upload(ctx, 0, *p_Ct);
+        vr_volume_normalize(ctx, 0, 0, nullptr);
+    } else {
+        p_Ct->NormalizeData();
+    }
     ComputeRecommendedSteppingParams(*p_Ct);
     p_OpacityTf = std::make_unique<OpacityTF>(m_TfRes);
     p_OpacityTf->SetDataRange(static_cast<int>(p_Ct->GetDataRange()));
     p_ColorTf = std::make_unique<ColorTF>(m_TfRes);
-    Upload(ctx, 0, *p_Ct);
+    if (!onDevice) Upload(ctx, 0, *p_Ct);
     p_OpacityTf->BindTexture(ctx, 0);
     p_ColorTf->BindTexture(ctx, 0);
     OnUpdate();
@@ -25,14 +31,21 @@ void BasicVolumeApp::OnUpdate()
 // ---- BasicVolLightApp (App/src/miniapps/BasicVolLightApp.cpp:12-51) ---------------------------------------------
 void BasicVolLightApp::OnStart(vr_ctx* ctx)
 {
-    p_Ct->NormalizeData();
-    p_Ct->PreComputeGradient();
-    p_Ct->AverageGradient(5);
+    const bool onDevice = m_PrepareOnDevice && !p_Ct->IsNormalized() && !p_Ct->HasGradient();
+    if (onDevice) {
+        Upload(ctx, 0, *p_Ct);
+        vr_volume_normalize(ctx, 0, 0, nullptr);
+        vr_volume_precompute_gradient(ctx, 0, 0);
+    } else {
+        p_Ct->NormalizeData();
+        p_Ct->PreComputeGradient();
+        p_Ct->AverageGradient(5);
+    }
     ComputeRecommendedSteppingParams(*p_Ct);
     p_OpacityTf = std::make_unique<OpacityTF>(m_TfRes);
     p_ColorTf = std::make_unique<ColorTF>(m_TfRes);
     p_OpacityTf->SetDataRange(static_cast<int>(p_Ct->GetMaxNumber()));
-    Upload(ctx, 0, *p_Ct);
+    if (!onDevice) Upload(ctx, 0, *p_Ct);
     p_OpacityTf->BindTexture(ctx, 0);
     p_ColorTf->BindTexture(ctx, 0);
     OnUpdate();

@@ -172,6 +172,7 @@ int vrh_app_start(void* a, int variant, void* v0, void* v1, void* v2, int tf_res
         return VR_ERR_INVALID_ARG;
     }
 }
+void vrh_app_set_prepare_on_device(void* a, int on) { static_cast<Application*>(a)->m_PrepareOnDevice = on != 0; }
 int vrh_app_update(void* a) { VRH_TRY(VR_ERR_HIP, { return static_cast<Application*>(a)->OnUpdate(); }) }
 int vrh_app_render(void* a) { VRH_TRY(VR_ERR_HIP, { return static_cast<Application*>(a)->OnRender(); }) }
 int vrh_app_resize(void* a, uint32_t w, uint32_t h) { VRH_TRY(VR_ERR_HIP, { return static_cast<Application*>(a)->OnResize(w, h); }) }

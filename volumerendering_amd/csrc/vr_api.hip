@@ -3,6 +3,7 @@
 // device vr_create fails with VR_ERR_HIP.
 #include "../../include/vr.h"
 #include "vr_kernels.h"
+#include "vr_wtb.h"
 
 #include <cstdio>
 #include <cstring>
@@ -201,7 +202,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     const bool skip_variant = variant == VR_VARIANT_BASIC || variant == VR_VARIANT_LIGHT ||
                               variant == VR_VARIANT_THREE_FILES || variant == VR_VARIANT_VOLUME_MASK;
     const int sv = (variant == VR_VARIANT_VOLUME_MASK) ? 2 : 0;  // the volume whose density drives tf[0]'s opacity
-    bool can_skip = skip_variant && c->flavour != 1 && c->vol_brick_max[sv] && c->tf_zero_prefix[0] >= 0 &&
+    bool can_skip = skip_variant && c->flavour != 1 && c->flavour != 2 && c->vol_brick_max[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
     if (variant == VR_VARIANT_THREE_FILES) can_skip = can_skip && c->tf_color_finite[1] && c->tf_opacity_finite[1];
     if (variant == VR_VARIANT_VOLUME_MASK)  // mask and CT must share one grid so that one brick index serves both
@@ -242,6 +243,17 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
             VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
         }
+        // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
+        const bool wtb = (c->flavour == 2 || c->flavour == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
+        if (wtb) {  // same grid as the default kernel
+            if (P.brick_max) {
+                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, P);
+                else hipLaunchKernelGGL((march_wtb_light_kernel<false, true>), grid, dim3(256), 0, s, P);
+            } else {
+                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, false>), grid, dim3(256), 0, s, P);
+                else hipLaunchKernelGGL((march_wtb_light_kernel<false, false>), grid, dim3(256), 0, s, P);
+            }
+        } else
         switch (variant) {
         case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, grid, s, P); break;
         case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, grid, s, P); break;
@@ -752,7 +764,7 @@ int vr_last_counters(vr_ctx* c, uint64_t out[3])
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour != 0 && flavour != 1) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 3) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

@@ -50,7 +50,7 @@ def load() -> C.CDLL:
         "vrh_camera_key": (None, [vp, i32]), "vrh_camera_get": (None, [vp, vp]),
         "vrh_app_create": (vp, [u32, u32, i32]), "vrh_app_free": (None, [vp]), "vrh_app_ok": (i32, [vp]),
         "vrh_app_error": (C.c_char_p, [vp]), "vrh_app_context": (vp, [vp]), "vrh_app_camera": (vp, [vp]),
-        "vrh_app_start": (i32, [vp, i32, vp, vp, vp, i32]), "vrh_app_update": (i32, [vp]), "vrh_app_render": (i32, [vp]),
+        "vrh_app_start": (i32, [vp, i32, vp, vp, vp, i32]), "vrh_app_set_prepare_on_device": (None, [vp, i32]), "vrh_app_update": (i32, [vp]), "vrh_app_render": (i32, [vp]),
         "vrh_app_resize": (i32, [vp, u32, u32]), "vrh_app_read_frame": (i32, [vp, vp, vp, C.POINTER(u64)]),
         "vrh_app_set_params": (None, [vp, i32, i32, f32, vp, vp]),
         "vrh_app_get_stepping": (None, [vp, C.POINTER(i32), C.POINTER(f32)]),
@@ -310,8 +310,9 @@ class Application:
     def camera(self) -> Camera:
         return Camera(0, 0, handle=self.lib.vrh_app_camera(self.h))
 
-    def OnStart(self, variant: int, volumes, tf_res: int = 0):
+    def OnStart(self, variant: int, volumes, tf_res: int = 0, prepare_on_device: bool = False):
         self._keep = list(volumes)
+        self.lib.vrh_app_set_prepare_on_device(self.h, int(prepare_on_device))
         hs = [v.h if v is not None else None for v in volumes] + [None, None, None]
         self._chk(self.lib.vrh_app_start(self.h, variant, hs[0], hs[1], hs[2], tf_res))
 
