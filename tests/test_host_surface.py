@@ -231,3 +231,21 @@ def test_camera_interaction_rules():
 def test_stepping_params():
     assert hr.stepping_params(512, 512, 512)[1] == 886 and hr.stepping_params(64, 64, 64)[1] == 110
     assert hr.stepping_params(1024, 100, 3)[1] == 1773 and hr.stepping_params(256, 256, 256)[1] == 443
+
+
+def test_dat_reader_round_trip(tmp_path):
+    """med::DatImpl (DatReader.cpp:11-46): 3 x uint16 header + uint16 voxels; the voxels land in the FIRST x*y*z
+    vec4 entries (the reference appends them behind `res` zero entries)."""
+    raw = hr.ct_phantom_raw(12)[:5, :7, :]          # nz=5, ny=7, nx=12
+    p = str(tmp_path / "vol.dat")
+    assert host.VolumeFile.write_dat(p, raw)
+    blob = open(p, "rb").read()
+    assert len(blob) == 6 + 2 * raw.size and blob[:6] == np.array([12, 7, 5], dtype="<u2").tobytes()
+    vf = host.VolumeFile.from_dat(p)
+    assert vf.GetSize() == (12, 7, 5) and vf.GetMaxNumber() == int(raw.max())
+    assert np.array_equal(vf.data(), hr.raw_to_vec4(raw))
+    with pytest.raises(IOError):
+        host.VolumeFile.from_dat(str(tmp_path / "missing.dat"))
+    open(p, "wb").write(blob[:100])                  # truncated
+    with pytest.raises(IOError):
+        host.VolumeFile.from_dat(p)

@@ -1,5 +1,5 @@
-// Mirrors App/src/file/FileDataType.h: what kind of data a VolumeFile holds.
+// Mirrors App/src/file/FileDataType.h: element type of the source data a VolumeFile was built from.
 #pragma once
 namespace med {
-enum class FileDataType { Undefined, DicomCT, DicomMR, DicomRTDose, DicomRTStruct, Dat, Synthetic };
+enum class FileDataType { Undefined, Uint8, Uint16, Uint32, Float, Double };
 }

@@ -23,8 +23,8 @@ public:
 
     // Builds the vec4 voxels the way the readers do: the raw integer broadcast to all four lanes
     // (DicomReader.cpp:239,247; DatReader.cpp:42).
-    static VolumeFile FromRaw(const std::uint16_t* raw, Size size, FileDataType type = FileDataType::Synthetic);
-    static VolumeFile FromRaw(const std::uint32_t* raw, Size size, FileDataType type = FileDataType::Synthetic);
+    static VolumeFile FromRaw(const std::uint16_t* raw, Size size, FileDataType type = FileDataType::Undefined);
+    static VolumeFile FromRaw(const std::uint32_t* raw, Size size, FileDataType type = FileDataType::Undefined);
 
     void PreComputeGradient(bool normToZeroOne = false);  // VolumeFile.cpp:196-257
     void PreComputeGradientSobel();                       // VolumeFile.cpp:77-117 (never called by the reference)

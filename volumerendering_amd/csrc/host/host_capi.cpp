@@ -6,6 +6,7 @@
 #include <string>
 
 #include "Application.h"
+#include "DatReader.h"
 
 using namespace med;
 
@@ -34,8 +35,16 @@ void* vrh_volume_from_vec4(const float* vec4, int nx, int ny, int nz, uint64_t m
         size_t n = (size_t)nx * ny * nz;
         std::vector<vrm::vec4> data(n);
         std::memcpy(static_cast<void*>(data.data()), vec4, n * sizeof(vrm::vec4));
-        return new VolumeHandle{std::make_shared<VolumeFile>("", sz(nx, ny, nz), FileDataType::Synthetic, data, (size_t)max_number)};
+        return new VolumeHandle{std::make_shared<VolumeFile>("", sz(nx, ny, nz), FileDataType::Float, data, (size_t)max_number)};
     })
+}
+void* vrh_volume_from_dat(const char* path)
+{
+    VRH_TRY(nullptr, { return new VolumeHandle{std::make_shared<VolumeFile>(DatImpl().ReadFile(path, false))}; })
+}
+int vrh_dat_write(const char* path, const uint16_t* raw, int nx, int ny, int nz)
+{
+    VRH_TRY(0, { return DatImpl::WriteFile(path, raw, (uint16_t)nx, (uint16_t)ny, (uint16_t)nz) ? 1 : 0; })
 }
 void vrh_volume_free(void* h) { delete static_cast<VolumeHandle*>(h); }
 void vrh_volume_normalize(void* h, int value) { static_cast<VolumeHandle*>(h)->v->NormalizeData(value); }

@@ -26,7 +26,8 @@ def load() -> C.CDLL:
     vp, i32, u32, u64, f32, f64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float, C.c_double
     sigs = {
         "vrh_volume_from_raw16": (vp, [vp, i32, i32, i32]), "vrh_volume_from_raw32": (vp, [vp, i32, i32, i32]),
-        "vrh_volume_from_vec4": (vp, [vp, i32, i32, i32, u64]), "vrh_volume_free": (None, [vp]),
+        "vrh_volume_from_vec4": (vp, [vp, i32, i32, i32, u64]), "vrh_volume_from_dat": (vp, [C.c_char_p]),
+        "vrh_dat_write": (i32, [C.c_char_p, vp, i32, i32, i32]), "vrh_volume_free": (None, [vp]),
         "vrh_volume_normalize": (None, [vp, i32]), "vrh_volume_gradient": (None, [vp, i32]),
         "vrh_volume_average_gradient": (None, [vp, i32]), "vrh_volume_data": (vp, [vp]),
         "vrh_volume_max_number": (u64, [vp]), "vrh_volume_data_range": (u64, [vp]),
@@ -89,6 +90,20 @@ class VolumeFile:
         v = np.ascontiguousarray(vec4, dtype=np.float32)
         nz, ny, nx = v.shape[:3]
         return cls(lib.vrh_volume_from_vec4(v.ctypes.data, nx, ny, nz, max_number))
+
+    @classmethod
+    def from_dat(cls, path: str):
+        """med::DatImpl::ReadFile: 6-byte uint16 header (x, y, z) + uint16 voxels."""
+        h = load().vrh_volume_from_dat(path.encode())
+        if not h:
+            raise IOError(f"Check file: {path}")
+        return cls(h)
+
+    @staticmethod
+    def write_dat(path: str, raw: np.ndarray) -> bool:
+        raw = np.ascontiguousarray(raw, dtype=np.uint16)
+        nz, ny, nx = raw.shape
+        return bool(load().vrh_dat_write(path.encode(), raw.ctypes.data, nx, ny, nz))
 
     def close(self):
         if self.h:
