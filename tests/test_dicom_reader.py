@@ -1,0 +1,106 @@
+"""med::DicomReader::ReadVolumeFile re-implemented without the `dcm` library (csrc/host/dicom/): synthetic series
+written by tests/dicom_writer.py are read back; semantics follow App/src/file/dicom/DicomReader.cpp."""
+import numpy as np
+import pytest
+
+import dicom_writer as dw
+import host_ref as hr
+from volumerendering_amd import host, synth
+
+
+def series(tmp_path, raw, explicit=True, shuffle=True, **kw):
+    d = tmp_path / ("series_e" if explicit else "series_i")
+    d.mkdir()
+    nz, ny, nx = raw.shape   # the file stores Rows x Columns; the reader maps X <- Rows, Y <- Columns
+    order = list(range(nz))
+    if shuffle:
+        order = order[::-1]
+    for k in order:
+        # file names sort in the WRONG order on purpose: InstanceNumber decides (SortDicomSlices)
+        dw.write_slice(str(d / f"img{nz - k:03d}.dcm"), raw[k], rows=nx, cols=ny, instance=k + 1, position=(0, 0, float(k)),
+                       explicit=explicit, **kw)
+    (d / "notes.txt").write_text("ignored")
+    return str(d)
+
+
+@pytest.mark.parametrize("explicit", [True, False])
+def test_ct_series_directory(tmp_path, explicit):
+    raw = synth.ct_phantom_raw(12)[:5]          # 5 slices of 12 x 12
+    path = series(tmp_path, raw, explicit=explicit, spacing=(0.8, 0.9), thickness=2.5, largest=3000)
+    vf = host.VolumeFile.from_dicom(path)
+    assert vf.GetSize() == (12, 12, 5)
+    assert np.array_equal(vf.data(), hr.raw_to_vec4(raw))      # slices in InstanceNumber order, raw value in all lanes
+    p = vf.dicom_params()
+    assert p["Modality"] == "CT" and (p["X"], p["Y"], p["Z"]) == (12, 12, 5)
+    assert p["BitsAllocated"] == 16 and p["SliceThickness"] == 2.5 and p["PixelSpacing"] == [0.8, 0.9]
+    assert p["FrameOfReference"] == "1.2.3.4" and p["MainAxis"] == "Z"
+    assert vf.GetMaxNumber() == 3000                           # LargestPixelValue wins over the data maximum
+    # pixel <-> RCS: identity orientation, origin of the FIRST slice read, column spacing on x / row spacing on y
+    assert vf.dicom_transform(0, (2.0, 3.0)) == pytest.approx((2 * 0.9, 3 * 0.8, 0.0))
+    assert vf.dicom_transform(1, (1.8, 2.4, 0.0))[:2] == pytest.approx((2.0, 3.0))
+    assert vf.dicom_transform(2, (1.8, 2.4, 5.0)) == pytest.approx((2.0, 3.0, 2.0))
+    bx, by, bz = vf.GetBBOXSize()                              # millimetre extents (VolumeFileDcm.cpp:50-59)
+    mm = [13 * 0.8, 13 * 0.9, 5 * 2.5]
+    assert (bx, by, bz) == pytest.approx(tuple(int(v / max(mm) * 100 + .5) / 100 for v in mm))
+    vf.NormalizeData()
+    assert float(vf.data()[..., 3].max()) == pytest.approx(raw.max() / 3000)
+
+
+def test_multiframe_rtdose_32bit_and_max(tmp_path):
+    dose = synth.dose_raw(10, 8, 6)                             # nz=6, ny=8, nx=10, uint32
+    f = str(tmp_path / "dose.dcm")
+    dw.write_slice(f, dose, modality="RTDOSE", rows=10, cols=8, frames=6, bits=32, position=(-5, -4, 1),
+                   orientation=(1, 0, 0, 0, 1, 0), frame_uid="9.9")
+    vf = host.VolumeFile.from_dicom(f)
+    assert vf.GetSize() == (10, 8, 6) and vf.dicom_params()["Modality"] == "RTDOSE"
+    assert np.array_equal(vf.data(), hr.raw_to_vec4(dose))
+    assert vf.GetMaxNumber() == int(dose.max())                # no LargestPixelValue tag: computed from the data
+    ct = host.VolumeFile.from_dicom(series(tmp_path, synth.ct_phantom_raw(8)[:2]))
+    lib = host.load()
+    assert lib.vrh_dicom_compare(ct.h, vf.h, 0) == 0           # different frame of reference
+    assert lib.vrh_dicom_compare(ct.h, vf.h, 1) == 1           # same orientation
+    assert lib.vrh_dicom_modality(f.encode()) == 3
+
+
+def test_single_slice_and_errors(tmp_path):
+    raw = synth.ct_phantom_raw(8)[3:4]
+    f = str(tmp_path / "one.dcm")
+    dw.write_slice(f, raw[0], modality="mr", rows=8, cols=8)
+    vf = host.VolumeFile.from_dicom(f)
+    assert vf.GetSize() == (8, 8, 1) and vf.dicom_params()["Modality"] == "MR"   # modality is not case sensitive
+    with pytest.raises(IOError, match="not a dicom file"):
+        host.VolumeFile.from_dicom(str(tmp_path / "one.txt"))
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(IOError, match="No dicom files"):
+        host.VolumeFile.from_dicom(str(empty))
+    bad = tmp_path / "bad.dcm"
+    bad.write_bytes(b"\0" * 200)
+    with pytest.raises(IOError, match="unable to open"):
+        host.VolumeFile.from_dicom(str(bad))
+    odd = str(tmp_path / "odd.dcm")
+    dw.write_slice(odd, raw[0], rows=8, cols=8, bits=8)
+    with pytest.raises(IOError, match="Unknown type"):
+        host.VolumeFile.from_dicom(odd)
+    # compressed transfer syntax is rejected, not mis-read
+    blob = open(f, "rb").read().replace(b"1.2.840.10008.1.2.1\0", b"1.2.840.10008.1.2.4.50")
+    comp = tmp_path / "jpeg.dcm"
+    comp.write_bytes(blob)
+    with pytest.raises(IOError, match="unable to open"):
+        host.VolumeFile.from_dicom(str(comp))
+
+
+@pytest.mark.gpu
+def test_dicom_series_renders_like_raw(tmp_path):
+    """A series read by DicomReader feeds the scene exactly like the same voxels handed over directly."""
+    import vrtest as vt
+    from volumerendering_amd import capi
+    raw = synth.ct_phantom_raw(16)
+    frames = []
+    for vol in (host.VolumeFile.from_dicom(series(tmp_path, raw, largest=int(raw.max()))), host.VolumeFile.from_raw(raw)):
+        with host.Application(80, 60, 0) as app:
+            app.OnStart(capi.LIGHT, [vol], tf_res=128)
+            app.camera().SetOrbit(0.35, 0.6, 1.2)
+            app.OnUpdate(); app.OnRender()
+            frames.append(app.ReadFrame()[0])
+    assert np.array_equal(vt.bits(frames[0]), vt.bits(frames[1])) and frames[0][..., 3].max() > 0

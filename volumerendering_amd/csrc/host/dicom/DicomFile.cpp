@@ -1,0 +1,185 @@
+#include "DicomFile.h"
+
+#include <cstring>
+#include <fstream>
+
+namespace med::dcmlite {
+
+namespace {
+constexpr std::uint32_t kUndefined = 0xFFFFFFFFu;
+constexpr Tag kItem = 0xFFFEE000, kItemDelim = 0xFFFEE00D, kSeqDelim = 0xFFFEE0DD;
+
+inline std::uint16_t rd16(const unsigned char* p) { return static_cast<std::uint16_t>(p[0] | (p[1] << 8)); }
+inline std::uint32_t rd32(const unsigned char* p)
+{
+    return static_cast<std::uint32_t>(p[0]) | (static_cast<std::uint32_t>(p[1]) << 8) |
+           (static_cast<std::uint32_t>(p[2]) << 16) | (static_cast<std::uint32_t>(p[3]) << 24);
+}
+inline bool long_vr(const unsigned char* vr)
+{
+    static const char* kLong[] = {"OB", "OD", "OF", "OL", "OV", "OW", "SQ", "UC", "UN", "UR", "UT"};
+    for (const char* l : kLong)
+        if (vr[0] == l[0] && vr[1] == l[1]) return true;
+    return false;
+}
+}  // namespace
+
+bool DicomFile::Load()
+{
+    m_Elements.clear();
+    std::ifstream f(m_Path, std::ios::binary);
+    if (!f) {
+        m_Error = "cannot open file";
+        return false;
+    }
+    m_Bytes.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    if (m_Bytes.size() < 132 || std::memcmp(m_Bytes.data() + 128, "DICM", 4) != 0) {
+        m_Error = "not a DICOM Part 10 file";
+        return false;
+    }
+    // file meta information (group 0002) is always Explicit VR Little Endian
+    size_t pos = 132;
+    if (!ParseDataset(pos, m_Bytes.size(), /*explicitVr=*/true, /*topLevel=*/true, &pos)) return false;
+    std::string ts = GetString(tags::kTransferSyntaxUID);
+    bool explicitVr;
+    if (ts == "1.2.840.10008.1.2.1") explicitVr = true;
+    else if (ts == "1.2.840.10008.1.2" || ts.empty()) explicitVr = false;
+    else {
+        m_Error = "unsupported transfer syntax " + ts + " (only uncompressed little endian)";
+        return false;
+    }
+    return ParseDataset(pos, m_Bytes.size(), explicitVr, true, &pos);
+}
+
+// Parses elements from pos; at top level it stops after the meta group when asked to switch syntax (group > 0002
+// seen while parsing the meta header), otherwise at `end` or at an item delimiter (nested use).
+bool DicomFile::ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLevel, size_t* stop)
+{
+    const bool metaPass = topLevel && m_Elements.empty();
+    while (pos + 8 <= end) {
+        const unsigned char* p = m_Bytes.data() + pos;
+        const Tag tag = (static_cast<Tag>(rd16(p)) << 16) | rd16(p + 2);
+        if (metaPass && (tag >> 16) != 0x0002) break;  // end of the file meta group
+        if (tag == kItemDelim || tag == kSeqDelim) {
+            pos += 8;
+            *stop = pos;
+            return true;
+        }
+        std::uint32_t length;
+        bool isSeq = false;
+        size_t header;
+        if (explicitVr && (tag >> 16) != 0xFFFE) {
+            const unsigned char* vr = p + 4;
+            if (long_vr(vr)) {
+                if (pos + 12 > end) break;
+                length = rd32(p + 8);
+                header = 12;
+            } else {
+                length = rd16(p + 6);
+                header = 8;
+            }
+            isSeq = vr[0] == 'S' && vr[1] == 'Q';
+        } else {
+            length = rd32(p + 4);
+            header = 8;
+            isSeq = length == kUndefined && tag != tags::kPixelData;  // implicit VR: only undefined lengths need walking
+        }
+        pos += header;
+        if (isSeq || (length == kUndefined && tag != tags::kPixelData)) {
+            if (!SkipSequence(&pos, end, length, explicitVr)) return false;
+            continue;
+        }
+        if (length == kUndefined) {
+            m_Error = "encapsulated (compressed) pixel data is not supported";
+            return false;
+        }
+        if (pos + length > end) {
+            m_Error = "element runs past the end of the file";
+            return false;
+        }
+        if (topLevel) m_Elements[tag] = Element{pos, length};
+        pos += length;
+    }
+    *stop = pos;
+    return true;
+}
+
+bool DicomFile::SkipSequence(size_t* pos, size_t end, std::uint32_t length, bool explicitVr)
+{
+    if (length != kUndefined) {
+        if (*pos + length > end) {
+            m_Error = "sequence runs past the end of the file";
+            return false;
+        }
+        *pos += length;
+        return true;
+    }
+    // undefined length: items until the sequence delimiter
+    while (*pos + 8 <= end) {
+        const unsigned char* p = m_Bytes.data() + *pos;
+        const Tag tag = (static_cast<Tag>(rd16(p)) << 16) | rd16(p + 2);
+        const std::uint32_t len = rd32(p + 4);
+        *pos += 8;
+        if (tag == kSeqDelim) return true;
+        if (tag != kItem) {
+            m_Error = "malformed sequence";
+            return false;
+        }
+        if (len != kUndefined) {
+            if (*pos + len > end) {
+                m_Error = "item runs past the end of the file";
+                return false;
+            }
+            *pos += len;
+        } else {
+            size_t stop = *pos;
+            if (!ParseDataset(*pos, end, explicitVr, /*topLevel=*/false, &stop)) return false;
+            *pos = stop;
+        }
+    }
+    m_Error = "unterminated sequence";
+    return false;
+}
+
+bool DicomFile::GetString(Tag tag, std::string* value) const
+{
+    auto it = m_Elements.find(tag);
+    if (it == m_Elements.end()) return false;
+    const char* b = reinterpret_cast<const char*>(m_Bytes.data() + it->second.offset);
+    size_t n = it->second.length;
+    while (n > 0 && (b[n - 1] == ' ' || b[n - 1] == '\0')) --n;
+    value->assign(b, n);
+    return true;
+}
+
+bool DicomFile::GetUint16(Tag tag, std::uint16_t* value) const
+{
+    auto it = m_Elements.find(tag);
+    if (it == m_Elements.end() || it->second.length < 2) return false;
+    *value = rd16(m_Bytes.data() + it->second.offset);
+    return true;
+}
+
+bool DicomFile::GetUint16Array(Tag tag, std::vector<std::uint16_t>* values) const
+{
+    auto it = m_Elements.find(tag);
+    if (it == m_Elements.end()) return false;
+    const size_t n = it->second.length / 2;
+    values->resize(n);
+    const unsigned char* b = m_Bytes.data() + it->second.offset;
+    for (size_t i = 0; i < n; ++i) (*values)[i] = rd16(b + 2 * i);
+    return true;
+}
+
+bool DicomFile::GetUint32Array(Tag tag, std::vector<std::uint32_t>* values) const
+{
+    auto it = m_Elements.find(tag);
+    if (it == m_Elements.end()) return false;
+    const size_t n = it->second.length / 4;
+    values->resize(n);
+    const unsigned char* b = m_Bytes.data() + it->second.offset;
+    for (size_t i = 0; i < n; ++i) (*values)[i] = rd32(b + 4 * i);
+    return true;
+}
+
+}  // namespace med::dcmlite

@@ -1,0 +1,63 @@
+// DicomFile -- minimal DICOM Part 10 reader: what the volume path needs from the `dcm` library the reference
+// links (an un-vendored fork, .gitmodules:21-24; call sites DicomReader.cpp:70-72,177-213,237,245).  Supports the
+// uncompressed little-endian transfer syntaxes (Implicit VR 1.2.840.10008.1.2, Explicit VR 1.2.840.10008.1.2.1);
+// sequences (defined or undefined length) are skipped, encapsulated pixel data is rejected.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace med::dcmlite {
+
+using Tag = std::uint32_t;  // (group << 16) | element, as the reference's dcm::Tag constants
+namespace tags {
+constexpr Tag kTransferSyntaxUID = 0x00020010;
+constexpr Tag kModality = 0x00080060;
+constexpr Tag kSliceThickness = 0x00180050;
+constexpr Tag kInstanceNumber = 0x00200013;
+constexpr Tag kImagePositionPatient = 0x00200032;
+constexpr Tag kImageOrientationPatient = 0x00200037;
+constexpr Tag kFrameOfReference = 0x00200052;
+constexpr Tag kNumberOfFrames = 0x00280008;
+constexpr Tag kRows = 0x00280010;
+constexpr Tag kColumns = 0x00280011;
+constexpr Tag kPixelSpacing = 0x00280030;
+constexpr Tag kBitsAllocated = 0x00280100;
+constexpr Tag kBitsStored = 0x00280101;
+constexpr Tag kSmallestPixelValue = 0x00280106;
+constexpr Tag kLargestPixelValue = 0x00280107;
+constexpr Tag kPixelData = 0x7FE00010;
+}  // namespace tags
+
+class DicomFile {
+public:
+    explicit DicomFile(std::string path) : m_Path(std::move(path)) {}
+    bool Load();  // false: unreadable, not Part 10, unsupported transfer syntax, malformed
+    const std::string& Error() const { return m_Error; }
+
+    bool GetString(Tag tag, std::string* value) const;  // trailing spaces / NULs trimmed
+    std::string GetString(Tag tag) const
+    {
+        std::string s;
+        GetString(tag, &s);
+        return s;
+    }
+    bool GetUint16(Tag tag, std::uint16_t* value) const;
+    bool GetUint16Array(Tag tag, std::vector<std::uint16_t>* values) const;
+    bool GetUint32Array(Tag tag, std::vector<std::uint32_t>* values) const;
+
+private:
+    struct Element {
+        size_t offset = 0;
+        std::uint32_t length = 0;
+    };
+    bool ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLevel, size_t* stop);
+    bool SkipSequence(size_t* pos, size_t end, std::uint32_t length, bool explicitVr);
+
+    std::string m_Path, m_Error;
+    std::vector<unsigned char> m_Bytes;
+    std::map<Tag, Element> m_Elements;  // top-level, non-sequence elements
+};
+
+}  // namespace med::dcmlite

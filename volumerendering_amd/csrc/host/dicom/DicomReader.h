@@ -1,0 +1,41 @@
+// DicomReader -- reads a CT / MR / RTDOSE series (a directory of single-frame .dcm slices, or one multi-frame
+// file) into a VolumeFileDcm.  Mirrors med::DicomReader::ReadVolumeFile and helpers
+// (App/src/file/dicom/DicomReader.{h,cpp}); the `dcm` library is replaced by dicom/DicomFile.  RTSTRUCT parsing
+// (ReadStructFile / Create3DMask) is not built yet.
+#pragma once
+#include <filesystem>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "DicomFile.h"
+#include "VolumeFileDcm.h"
+
+namespace med {
+
+class DicomReader {
+public:
+    // Throws std::runtime_error on: not a .dcm file, empty directory, unreadable / unsupported file, unknown
+    // BitsAllocated (the reference throws MSVC-only std::exception("..."), DicomReader.cpp:52,63,87,313).
+    [[nodiscard]] static std::shared_ptr<VolumeFileDcm> ReadVolumeFile(std::filesystem::path name);
+    [[nodiscard]] static DicomModality CheckModality(const std::filesystem::path& name);
+    [[nodiscard]] static DicomModality ResolveModality(std::string modality);  // not case sensitive
+    [[nodiscard]] static std::string ResolveModality(DicomModality modality);
+    [[nodiscard]] static std::vector<std::filesystem::path> SortDicomSlices(const std::vector<std::filesystem::path>& paths);
+    [[nodiscard]] static bool IsDicomFile(const std::filesystem::path& path) { return path.extension() == ".dcm"; }
+
+private:
+    void ReadDicomVolumeVariables(const dcmlite::DicomFile& f);
+    void ReadData(const dcmlite::DicomFile& f);
+    void ResolveFileType();
+
+    DicomVolumeParams m_Params;
+    FileDataType m_FileDataType = FileDataType::Undefined;
+    std::vector<vrm::vec4> m_Data;
+};
+
+// "1\\0\\0" -> numbers; missing / unparsable entries stay 0 (DicomParseUtil.inl:15-80)
+template <typename T, size_t N>
+std::array<T, N> ParseStringToNumArr(const std::string& str);
+
+}  // namespace med

@@ -7,11 +7,15 @@
 
 #include "Application.h"
 #include "DatReader.h"
+#include "dicom/DicomReader.h"
 
 using namespace med;
 
 namespace {
-struct VolumeHandle { std::shared_ptr<VolumeFile> v; };
+struct VolumeHandle {
+    std::shared_ptr<VolumeFile> v;
+    std::shared_ptr<VolumeFileDcm> dcm;  // set when the volume came from DicomReader
+};
 VolumeFile::Size sz(int nx, int ny, int nz) { return {(uint16_t)nx, (uint16_t)ny, (uint16_t)nz}; }
 }  // namespace
 
@@ -46,6 +50,54 @@ int vrh_dat_write(const char* path, const uint16_t* raw, int nx, int ny, int nz)
 {
     VRH_TRY(0, { return DatImpl::WriteFile(path, raw, (uint16_t)nx, (uint16_t)ny, (uint16_t)nz) ? 1 : 0; })
 }
+// DicomReader::ReadVolumeFile; on failure returns NULL and writes the message to err
+void* vrh_volume_from_dicom(const char* path, char* err, int errlen)
+{
+    try {
+        auto d = DicomReader::ReadVolumeFile(path);
+        return new VolumeHandle{d, d};
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) {
+            std::strncpy(err, e.what(), (size_t)errlen - 1);
+            err[errlen - 1] = 0;
+        }
+        return nullptr;
+    }
+}
+// out: modality, X, Y, Z, BitsStored, BitsAllocated, Largest, Smallest, SliceThickness, pos[3], orient[6], spacing[2]
+int vrh_dicom_params(void* h, double* out, char* main_axis, char* frame_of_reference, int len)
+{
+    auto* vh = static_cast<VolumeHandle*>(h);
+    if (!vh->dcm) return 0;
+    const DicomVolumeParams p = vh->dcm->GetVolumeParams();
+    int i = 0;
+    out[i++] = (double)(int)p.Modality; out[i++] = p.X; out[i++] = p.Y; out[i++] = p.Z;
+    out[i++] = p.BitsStored; out[i++] = p.BitsAllocated; out[i++] = p.LargestPixelValue; out[i++] = p.SmallestPixelValue;
+    out[i++] = p.SliceThickness;
+    for (double v : p.ImagePositionPatient) out[i++] = v;
+    for (double v : p.ImageOrientationPatient) out[i++] = v;
+    for (double v : p.PixelSpacing) out[i++] = v;
+    std::strncpy(main_axis, p.MainAxis.c_str(), 7);
+    main_axis[7] = 0;
+    std::strncpy(frame_of_reference, p.FrameOfReference.c_str(), (size_t)len - 1);
+    frame_of_reference[len - 1] = 0;
+    return 1;
+}
+// which: 0 PixelToRCS (in[0..1]), 1 RCSToPixel, 2 RCSToVoxel
+void vrh_dicom_transform(void* h, int which, const float* in, float* out)
+{
+    auto* d = static_cast<VolumeHandle*>(h)->dcm.get();
+    if (which == 0) { vrm::vec3 r = d->PixelToRCSTransform({in[0], in[1]}); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+    else if (which == 1) { vrm::vec2 r = d->RCSToPixelTransform({in[0], in[1], in[2]}); out[0] = r.x; out[1] = r.y; out[2] = 0; }
+    else { vrm::vec3 r = d->RCSToVoxelTransform({in[0], in[1], in[2]}); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+}
+int vrh_dicom_compare(void* a, void* b, int which)
+{
+    auto* da = static_cast<VolumeHandle*>(a)->dcm.get();
+    auto* db = static_cast<VolumeHandle*>(b)->dcm.get();
+    return which == 0 ? da->CompareFrameOfReference(*db) : da->CompareOrientation(*db);
+}
+int vrh_dicom_modality(const char* path) { VRH_TRY(0, { return (int)DicomReader::CheckModality(path); }) }
 void vrh_volume_free(void* h) { delete static_cast<VolumeHandle*>(h); }
 void vrh_volume_normalize(void* h, int value) { static_cast<VolumeHandle*>(h)->v->NormalizeData(value); }
 void vrh_volume_gradient(void* h, int norm01) { static_cast<VolumeHandle*>(h)->v->PreComputeGradient(norm01 != 0); }

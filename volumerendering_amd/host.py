@@ -27,7 +27,10 @@ def load() -> C.CDLL:
     sigs = {
         "vrh_volume_from_raw16": (vp, [vp, i32, i32, i32]), "vrh_volume_from_raw32": (vp, [vp, i32, i32, i32]),
         "vrh_volume_from_vec4": (vp, [vp, i32, i32, i32, u64]), "vrh_volume_from_dat": (vp, [C.c_char_p]),
-        "vrh_dat_write": (i32, [C.c_char_p, vp, i32, i32, i32]), "vrh_volume_free": (None, [vp]),
+        "vrh_dat_write": (i32, [C.c_char_p, vp, i32, i32, i32]),
+        "vrh_volume_from_dicom": (vp, [C.c_char_p, C.c_char_p, i32]), "vrh_dicom_params": (i32, [vp, vp, C.c_char_p, C.c_char_p, i32]),
+        "vrh_dicom_transform": (None, [vp, i32, vp, vp]), "vrh_dicom_compare": (i32, [vp, vp, i32]),
+        "vrh_dicom_modality": (i32, [C.c_char_p]), "vrh_volume_free": (None, [vp]),
         "vrh_volume_normalize": (None, [vp, i32]), "vrh_volume_gradient": (None, [vp, i32]),
         "vrh_volume_average_gradient": (None, [vp, i32]), "vrh_volume_data": (vp, [vp]),
         "vrh_volume_max_number": (u64, [vp]), "vrh_volume_data_range": (u64, [vp]),
@@ -98,6 +101,33 @@ class VolumeFile:
         if not h:
             raise IOError(f"Check file: {path}")
         return cls(h)
+
+    @classmethod
+    def from_dicom(cls, path: str):
+        """med::DicomReader::ReadVolumeFile: a directory of .dcm slices or one (multi-frame) .dcm file."""
+        err = C.create_string_buffer(512)
+        h = load().vrh_volume_from_dicom(path.encode(), err, 512)
+        if not h:
+            raise IOError(err.value.decode())
+        return cls(h)
+
+    def dicom_params(self) -> dict:
+        out = (C.c_double * 20)()
+        axis, frame = C.create_string_buffer(8), C.create_string_buffer(128)
+        if not self.lib.vrh_dicom_params(self.h, out, axis, frame, 128):
+            raise ValueError("not a DICOM volume")
+        o = list(out)
+        return dict(Modality=["UNKNOWN", "CT", "RTSTRUCT", "RTDOSE", "MR", "CONTOURMASK"][int(o[0])], X=int(o[1]), Y=int(o[2]),
+                    Z=int(o[3]), BitsStored=int(o[4]), BitsAllocated=int(o[5]), LargestPixelValue=int(o[6]),
+                    SmallestPixelValue=int(o[7]), SliceThickness=o[8], ImagePositionPatient=o[9:12],
+                    ImageOrientationPatient=o[12:18], PixelSpacing=o[18:20], MainAxis=axis.value.decode(),
+                    FrameOfReference=frame.value.decode())
+
+    def dicom_transform(self, which: int, v):
+        a = (C.c_float * 3)(*(list(v) + [0.0])[:3])
+        o = (C.c_float * 3)()
+        self.lib.vrh_dicom_transform(self.h, which, a, o)
+        return tuple(o)
 
     @staticmethod
     def write_dat(path: str, raw: np.ndarray) -> bool:
