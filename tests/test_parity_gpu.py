@@ -308,3 +308,28 @@ def test_lds_wave_tile_flavours_are_exact(ctx, flavour):
         check(ctx, capi.LIGHT, u, [v], [tf], 64, 48)
     finally:
         ctx.set_kernel_flavour(0)
+
+
+def test_skipping_on_a_mostly_empty_volume(ctx):
+    """A 96^3 volume that is almost entirely exactly-zero air (long inert runs), cameras from many sides, clips and
+    variable step: the skipping kernel must equal the oracle and count the same samples."""
+    n = 96
+    raw = np.zeros((n, n, n), dtype=np.uint16)
+    raw[40:56, 30:70, 44:60] = 3000          # a slab in the middle: everything else is exactly-zero air
+    raw[10, 85, 20] = 2000                   # a lone voxel inside an otherwise inert super-brick
+    v = ob.precompute_gradient(ob.normalize_data(hr.raw_to_vec4(raw)))
+    tf = zero_prefix_tf(64, 2, top=0.05)
+    step, count = hr.stepping_params(n, n, n)
+    W, H = 72, 56
+    ctx.resize(W, H)
+    cams = [dict(yaw=0.6, pitch=0.35), dict(yaw=2.2, pitch=-0.6, distance=0.9), dict(yaw=-1.3, pitch=1.1),
+            dict(yaw=3.1, pitch=0.05, distance=2.0)]
+    for cam in cams:
+        for extra in (dict(), dict(clip_x=(0.1, 0.2), clip_y=(0.05, 0.0)), dict(toggles=(1, 0, 0, 0), steps_count=count // 2)):
+            kw = dict(steps_count=count, step_size=step)
+            kw.update(cam)
+            kw.update(extra)
+            u = hr.make_uniforms(W, H, **kw)
+            for variant in (capi.BASIC, capi.LIGHT):
+                frag, ns = check(ctx, variant, u, [v], [tf], W, H)
+                assert ctx.counters()[2] < 0.5 * ns
