@@ -104,7 +104,7 @@ def cpu_baseline(app, capi, variant, vols, W, H, budget_s=15.0):
         _, n = ob.render_pixels(variant, uo, volumes, tfs, W, H, pxy, nthreads=cores)
         dt = time.perf_counter() - t0
         value = n / dt / 1e9 if dt > 0 else 0.0
-        sample = (f"every {stride}th pixel in x and y of the {W}x{H} frame ({pxy.shape[0]} rays, {n} composited "
+        sample = (f"one pixel out of every {stride} x {stride} block of the {W}x{H} frame ({pxy.shape[0]} rays, {n} composited "
                   f"samples, {dt:.2f} s)")
         if dt >= budget_s / 4 or stride <= 2:
             break
