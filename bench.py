@@ -66,10 +66,11 @@ def build_scene(app, host, synth, capi, workload, tf_kind, vol_n=0):
         dose = host.VolumeFile.from_raw(synth.dose_raw())
         vols = [mask, dose, ct]
     app.OnStart(variant, vols)  # NormalizeData / PreComputeGradient in the scene's own order + uploads
-    if tf_kind == "thin":  # control points (0,0),(R-1,0.002): no ray terminates
+    if tf_kind in ("thin", "zero"):  # control points (0,0),(R-1,0.002): no ray terminates
         for which in range(2 if vname == "VOLUME_MASK" else 1):
             otf = app.scene_opacity_tf(which)
-            otf.SetControlPoint(1, otf.GetTextureResolution() - 1, 0.002)
+            # "zero" (experiment): opacity identically 0 -> every sample is an identity blend: pure traversal cost
+            otf.SetControlPoint(1, otf.GetTextureResolution() - 1, 0.002 if tf_kind == "thin" else 0.0)
     cam = app.camera()
     cam.SetOrbit(0.35, 0.6, 1.2)
     if vol_n:
@@ -118,7 +119,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--tf", default="default", choices=["default", "thin"])
+    ap.add_argument("--tf", default="default", choices=["default", "thin", "zero"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flavour", type=int, default=0)
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")

@@ -215,6 +215,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         P.bnx = (c->vol[sv].nx + 7) >> kBrickShift;
         P.bny = (c->vol[sv].ny + 7) >> kBrickShift;
         P.bnz = (c->vol[sv].nz + 7) >> kBrickShift;
+        P.bsx = (float)c->vol[sv].nx * 0.125f;
+        P.bsy = (float)c->vol[sv].ny * 0.125f;
+        P.bsz = (float)c->vol[sv].nz * 0.125f;
         P.tf_zero_prefix = c->tf_zero_prefix[0];
     }
 

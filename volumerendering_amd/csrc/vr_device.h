@@ -45,6 +45,7 @@ struct MarchParams {
     const float* brick_rgb;  // VOLUME_MASK only: per-brick max(r,g,b) of the mask (vol[0]); nullptr otherwise
     int skip_vol;            // which volume carries the density that drives the opacity (0, or 2 for VOLUME_MASK)
     int bnx, bny, bnz;       // bricks per axis
+    float bsx, bsy, bsz;     // n/8 per axis of vol[skip_vol] (exact in f32)
     int tf_zero_prefix;      // largest Z with opacity[0..Z] == 0 exactly (-1: none)
     float4* out;
     unsigned long long* counters;  // [0] composited samples, [1] covered pixels, [2] samples actually fetched
