@@ -35,8 +35,9 @@ struct vr_ctx {
     hipStream_t stream = nullptr;
     DevVolume vol[VR_MAX_VOLUMES] = {};
     size_t vol_bytes[VR_MAX_VOLUMES] = {};
-    float* vol_brick_max[VR_MAX_VOLUMES] = {};  // per-brick max density (empty-space skipping)
-    float* vol_brick_rgb[VR_MAX_VOLUMES] = {};  // per-brick max(r,g,b)
+    float2* vol_bricks[VR_MAX_VOLUMES] = {};  // per brick: (max density, max(r,g,b)) -- empty-space skipping
+    float2* merged_bricks = nullptr;           // VOLUME_MASK: (CT density max, mask rgb max), rebuilt when stale
+    bool merged_stale = true;
     int tf_zero_prefix[VR_MAX_TFS] = {-1, -1};  // zero prefix of each opacity table, -1 if none / not finite
     bool tf_color_finite[VR_MAX_TFS] = {false, false};
     bool tf_opacity_finite[VR_MAX_TFS] = {false, false};
@@ -126,7 +127,7 @@ void launch_variant(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
     if constexpr (kCanSkip) {
-        if (P.brick_max) {
+        if (P.bricks) {
             if (off32)
                 hipLaunchKernelGGL((march_kernel<V, true, true>), grid, dim3(256), 0, s, P);
             else
@@ -202,15 +203,13 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     const bool skip_variant = variant == VR_VARIANT_BASIC || variant == VR_VARIANT_LIGHT ||
                               variant == VR_VARIANT_THREE_FILES || variant == VR_VARIANT_VOLUME_MASK;
     const int sv = (variant == VR_VARIANT_VOLUME_MASK) ? 2 : 0;  // the volume whose density drives tf[0]'s opacity
-    bool can_skip = skip_variant && c->flavour != 1 && c->flavour != 2 && c->vol_brick_max[sv] && c->tf_zero_prefix[0] >= 0 &&
+    bool can_skip = skip_variant && c->flavour != 1 && c->flavour != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
     if (variant == VR_VARIANT_THREE_FILES) can_skip = can_skip && c->tf_color_finite[1] && c->tf_opacity_finite[1];
     if (variant == VR_VARIANT_VOLUME_MASK)  // mask and CT must share one grid so that one brick index serves both
-        can_skip = can_skip && c->vol_brick_rgb[0] && c->vol[0].nx == c->vol[2].nx && c->vol[0].ny == c->vol[2].ny &&
+        can_skip = can_skip && c->vol_bricks[0] && c->vol[0].nx == c->vol[2].nx && c->vol[0].ny == c->vol[2].ny &&
                    c->vol[0].nz == c->vol[2].nz;
     if (can_skip) {
-        P.brick_max = c->vol_brick_max[sv];
-        P.brick_rgb = (variant == VR_VARIANT_VOLUME_MASK) ? c->vol_brick_rgb[0] : nullptr;
         P.skip_vol = sv;
         P.bnx = (c->vol[sv].nx + 7) >> kBrickShift;
         P.bny = (c->vol[sv].ny + 7) >> kBrickShift;
@@ -219,6 +218,22 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         P.bsy = (float)c->vol[sv].ny * 0.125f;
         P.bsz = (float)c->vol[sv].nz * 0.125f;
         P.tf_zero_prefix = c->tf_zero_prefix[0];
+        P.bricks = c->vol_bricks[sv];
+        P.use_rgb = 0;
+        if (variant == VR_VARIANT_VOLUME_MASK) {
+            const int nb = P.bnx * P.bny * P.bnz;
+            if (c->merged_stale || !c->merged_bricks) {
+                if (c->merged_bricks) (void)hipFree(c->merged_bricks);
+                c->merged_bricks = nullptr;
+                VR_HIP(c, hipMalloc(&c->merged_bricks, (size_t)nb * sizeof(float2)));
+                hipLaunchKernelGGL(merge_bricks_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, c->vol_bricks[2],
+                                   c->vol_bricks[0], c->merged_bricks, nb);
+                VR_HIP(c, hipGetLastError());
+                c->merged_stale = false;
+            }
+            P.bricks = c->merged_bricks;
+            P.use_rgb = 1;
+        }
     }
 
     if (packed && !out) {
@@ -249,7 +264,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
         const bool wtb = (c->flavour == 2 || c->flavour == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
         if (wtb) {  // same grid as the default kernel
-            if (P.brick_max) {
+            if (P.bricks) {
                 if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, P);
                 else hipLaunchKernelGGL((march_wtb_light_kernel<false, true>), grid, dim3(256), 0, s, P);
             } else {
@@ -287,16 +302,14 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
 int refresh_bricks(vr_ctx* c, int slot)
 {
     const DevVolume& v = c->vol[slot];
-    if (c->vol_brick_max[slot]) (void)hipFree(c->vol_brick_max[slot]);
-    if (c->vol_brick_rgb[slot]) (void)hipFree(c->vol_brick_rgb[slot]);
-    c->vol_brick_max[slot] = nullptr;
-    c->vol_brick_rgb[slot] = nullptr;
+    if (c->vol_bricks[slot]) (void)hipFree(c->vol_bricks[slot]);
+    c->vol_bricks[slot] = nullptr;
+    c->merged_stale = true;
     const int bnx = (v.nx + 7) >> kBrickShift, bny = (v.ny + 7) >> kBrickShift, bnz = (v.nz + 7) >> kBrickShift;
     const size_t nbricks = (size_t)bnx * bny * bnz;
-    VR_HIP(c, hipMalloc(&c->vol_brick_max[slot], nbricks * sizeof(float)));
-    VR_HIP(c, hipMalloc(&c->vol_brick_rgb[slot], nbricks * sizeof(float)));
+    VR_HIP(c, hipMalloc(&c->vol_bricks[slot], nbricks * sizeof(float2)));
     hipLaunchKernelGGL(brick_max_kernel, dim3((unsigned)nbricks), dim3(64), 0, c->stream, v.data, v.nx, v.ny, v.nz, bnx, bny,
-                       c->vol_brick_max[slot], c->vol_brick_rgb[slot]);
+                       c->vol_bricks[slot]);
     VR_HIP(c, hipGetLastError());
     VR_HIP(c, hipStreamSynchronize(c->stream));
     return VR_OK;
@@ -490,9 +503,8 @@ void vr_destroy(vr_ctx* c)
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
         if (c->vol[i].data) (void)hipFree(const_cast<float4*>(c->vol[i].data));
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
-        if (c->vol_brick_max[i]) (void)hipFree(c->vol_brick_max[i]);
-    for (int i = 0; i < VR_MAX_VOLUMES; ++i)
-        if (c->vol_brick_rgb[i]) (void)hipFree(c->vol_brick_rgb[i]);
+        if (c->vol_bricks[i]) (void)hipFree(c->vol_bricks[i]);
+    if (c->merged_bricks) (void)hipFree(c->merged_bricks);
     for (int i = 0; i < VR_MAX_TFS; ++i) {
         if (c->tf_opacity[i]) (void)hipFree(c->tf_opacity[i]);
         if (c->tf_color[i]) (void)hipFree(c->tf_color[i]);

@@ -41,8 +41,9 @@ struct MarchParams {
     int n_blocks;            // logical blocks = n_tiles * kBlocksPerTile (grid is padded to a multiple of 8)
     // exact empty-space skipping (BASIC / LIGHT / THREE_FILES): per-brick maximum density of vol[0] over the
     // 9x9x9 voxels an 8x8x8 block of base cells can touch, and the length of the opacity table's zero prefix
-    const float* brick_max;  // nullptr = disabled; maxima of vol[skip_vol].a
-    const float* brick_rgb;  // VOLUME_MASK only: per-brick max(r,g,b) of the mask (vol[0]); nullptr otherwise
+    const float2* bricks;    // nullptr = disabled; per brick: x = max of vol[skip_vol].a, y = max(r,g,b) of the mask
+                             // (y is filled from vol[0]'s bricks for VOLUME_MASK and is 0 otherwise)
+    int use_rgb;             // VOLUME_MASK: a brick is inert only if its mask record y <= 0
     int skip_vol;            // which volume carries the density that drives the opacity (0, or 2 for VOLUME_MASK)
     int bnx, bny, bnz;       // bricks per axis
     float bsx, bsy, bsz;     // n/8 per axis of vol[skip_vol] (exact in f32)

@@ -433,14 +433,13 @@ __device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
     int bz = clampi((int)floorf(p.z * P.bsz - 0.0625f), 0, P.bnz - 1);
     return (bz * P.bny + by) * P.bnx + bx;
 }
-__device__ __forceinline__ bool brick_inert(const MarchParams& P, int bid)
+__device__ __forceinline__ bool brick_inert(const MarchParams& P, float2 rec)
 {
-    float bm = P.brick_max[bid];
     // VOLUME_MASK: a mask sample with r, g or b > 0 switches to the RT table; if every mask voxel the brick can touch
     // has max(r,g,b) <= 0 the interpolated channels are <= 0 too, so the CT opacity is the one that is blended
-    if (P.brick_rgb && !(P.brick_rgb[bid] <= 0.0f)) return false;
-    if (bm <= 0.0f) return P.tf_zero_prefix >= 0;
-    return floorf(bm * (float)P.tf[0].res_o - 0.5f) + 2.0f <= (float)P.tf_zero_prefix;
+    if (P.use_rgb && !(rec.y <= 0.0f)) return false;
+    if (rec.x <= 0.0f) return P.tf_zero_prefix >= 0;
+    return floorf(rec.x * (float)P.tf[0].res_o - 0.5f) + 2.0f <= (float)P.tf_zero_prefix;
 }
 
 template <int V, bool OFF32, bool SKIP>
@@ -487,8 +486,6 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                 f3 w = ray.world0;
                 const float bx0 = P.bmin[0], by0 = P.bmin[1], bz0 = P.bmin[2];
                 const float bx1 = P.bmax[0], by1 = P.bmax[1], bz1 = P.bmax[2];
-                int cur_brick = -1;
-                bool cur_inert = false;
                 // Steps [0, n_inside) are certainly inside IsInSampleCoords: p moves monotonically per component
                 // (a rounded addition of a constant never moves against its sign), so the bound behind the ray
                 // holds for good once it holds at the start, and the bound ahead is far enough away by a margin
@@ -502,20 +499,24 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                     const float f = fminf(fminf(fx, fy), fminf(fz, 1.0e6f)) * 0.999f - 2.0f;
                     if (in0 && f > 0.0f) n_inside = (int)f;  // NaN / negative -> 0
                 }
+                // Empty-space test, software-pipelined and branch-free: every iteration loads the brick record of
+                // the NEXT position (the same rounded additions the advance performs, so it is the position the next
+                // iteration really has) and the record is consumed one iteration later.  With 64 rays per wavefront
+                // some lane enters a new brick almost every step; a load-and-wait inside a divergent branch would
+                // stall the whole wavefront each time, an unconditional load whose lanes hit the same one or two
+                // 64-byte lines does not.
+                float2 rec = make_float2(0.0f, 0.0f);
+                if constexpr (SKIP) rec = P.bricks[brick_of(P, p)];
                 for (int i = 0; i < P.steps_count; ++i) {
                     bool inb = true;
                     if (i >= n_inside)
                         inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
+                    const f3 pn = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                    float2 rec_next = rec;
+                    if constexpr (SKIP) rec_next = P.bricks[brick_of(P, pn)];
                     if (inb) {
                         bool inert = false;
-                        if constexpr (SKIP) {
-                            int bid = brick_of(P, p);
-                            if (bid != cur_brick) {  // one 4-byte lookup per brick entered, not per step
-                                cur_brick = bid;
-                                cur_inert = brick_inert(P, bid);
-                            }
-                            inert = cur_inert;
-                        }
+                        if constexpr (SKIP) inert = brick_inert(P, rec);
                         if (!inert) {
                             sample_and_blend<V, OFF32>(P, p, w, dst);
                             ++fetched;
@@ -529,7 +530,8 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                                     (step.z >= 0.0f && p.z > bz1) || (step.z <= 0.0f && p.z < bz0);
                         if (gone) break;
                     }
-                    p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                    p = pn;
+                    rec = rec_next;
                     if constexpr (V != V_BASIC && V != V_TF_CALIB) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
                 }
             }
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
 
 // One wavefront per brick: maximum of .a over the voxels [8b, min(8b+8, n-1)]^3 (NaN if any voxel is NaN).
 __global__ __launch_bounds__(64) void brick_max_kernel(const float4* __restrict__ vol, int nx, int ny, int nz, int bnx,
-                                                       int bny, float* __restrict__ out, float* __restrict__ out_rgb)
+                                                       int bny, float2* __restrict__ out)
 {
     const int b = blockIdx.x;
     const int bx = b % bnx, by = (b / bnx) % bny, bz = b / (bnx * bny);
@@ -578,10 +580,7 @@ __global__ __launch_bounds__(64) void brick_max_kernel(const float4* __restrict_
         has_nan = has_nan || (__shfl_down((int)has_nan, off, 64) != 0);
         has_nan_c = has_nan_c || (__shfl_down((int)has_nan_c, off, 64) != 0);
     }
-    if (threadIdx.x == 0) {
-        out[b] = has_nan ? NAN : m;
-        out_rgb[b] = has_nan_c ? NAN : mc;
-    }
+    if (threadIdx.x == 0) out[b] = make_float2(has_nan ? NAN : m, has_nan_c ? NAN : mc);
 }
 
 // ------------------------------------------------------------------------------------------------ aux kernels
@@ -617,6 +616,14 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4*
     int r = t % world, n = t / world;
     size_t src = ((size_t)r * tiles_per_rank_max + n) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile);
     frame[(size_t)y * W + x] = gathered[src];
+}
+
+// VOLUME_MASK looks at two volumes on one grid: record = (max density of the CT, max(r,g,b) of the mask)
+__global__ void merge_bricks_kernel(const float2* __restrict__ density_vol, const float2* __restrict__ mask_vol,
+                                    float2* __restrict__ out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float2(density_vol[i].x, mask_vol[i].y);
 }
 
 // ------------------------------------------------------------------------------------------------ data preparation
