@@ -205,6 +205,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     const int sv = (variant == VR_VARIANT_VOLUME_MASK) ? 2 : 0;  // the volume whose density drives tf[0]'s opacity
     bool can_skip = skip_variant && c->flavour != 1 && c->flavour != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
+    // the kernels index bricks with 24-bit multiplies and 32-bit byte offsets
+    can_skip = can_skip && ((c->vol[sv].nx + 7) >> kBrickShift) * (long long)((c->vol[sv].ny + 7) >> kBrickShift) < (1 << 23);
     if (variant == VR_VARIANT_THREE_FILES) can_skip = can_skip && c->tf_color_finite[1] && c->tf_opacity_finite[1];
     if (variant == VR_VARIANT_VOLUME_MASK)  // mask and CT must share one grid so that one brick index serves both
         can_skip = can_skip && c->vol_bricks[0] && c->vol[0].nx == c->vol[2].nx && c->vol[0].ny == c->vol[2].ny &&

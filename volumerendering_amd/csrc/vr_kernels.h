@@ -431,7 +431,12 @@ __device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
     int bx = clampi((int)floorf(p.x * P.bsx - 0.0625f), 0, P.bnx - 1);
     int by = clampi((int)floorf(p.y * P.bsy - 0.0625f), 0, P.bny - 1);
     int bz = clampi((int)floorf(p.z * P.bsz - 0.0625f), 0, P.bnz - 1);
-    return (bz * P.bny + by) * P.bnx + bx;
+    return __mul24(__mul24(bz, P.bny) + by, P.bnx) + bx;  // < 2^24 bricks per axis pair: 24-bit multiplies are exact
+}
+// record of brick `bid`: the table is far below 4 GiB, so SGPR base + 32-bit byte offset addressing
+__device__ __forceinline__ float2 brick_record(const MarchParams& P, int bid)
+{
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(P.bricks) + ((unsigned)bid << 3));
 }
 __device__ __forceinline__ bool brick_inert(const MarchParams& P, float2 rec)
 {
@@ -506,14 +511,14 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                 // stall the whole wavefront each time, an unconditional load whose lanes hit the same one or two
                 // 64-byte lines does not.
                 float2 rec = make_float2(0.0f, 0.0f);
-                if constexpr (SKIP) rec = P.bricks[brick_of(P, p)];
+                if constexpr (SKIP) rec = brick_record(P, brick_of(P, p));
                 for (int i = 0; i < P.steps_count; ++i) {
                     bool inb = true;
                     if (i >= n_inside)
                         inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
                     const f3 pn = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
                     float2 rec_next = rec;
-                    if constexpr (SKIP) rec_next = P.bricks[brick_of(P, pn)];
+                    if constexpr (SKIP) rec_next = brick_record(P, brick_of(P, pn));
                     if (inb) {
                         bool inert = false;
                         if constexpr (SKIP) inert = brick_inert(P, rec);
