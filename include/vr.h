@@ -219,7 +219,8 @@ int vr_last_covered_pixels(vr_ctx* ctx, uint64_t* covered);
 int vr_last_counters(vr_ctx* ctx, uint64_t out[3]);
 
 /* Kernel flavour for A/B measurements: 0 = default (best), 1 = no empty-space skipping, 2 = LDS wave tiles
- * without skipping, 3 = LDS wave tiles with skipping (lit shader only; others fall back to 0 / 1).  All
+ * without skipping, 3 = LDS wave tiles with skipping (lit shader only; others fall back to 0 / 1), 4 = skipping
+ * plus exact empty-space leaping (closed-form f32 accumulation over a brick distance field).  All
  * flavours are bit-identical in output and in the composited-sample count.                       */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 

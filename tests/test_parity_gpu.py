@@ -333,3 +333,36 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
             for variant in (capi.BASIC, capi.LIGHT):
                 frag, ns = check(ctx, variant, u, [v], [tf], W, H)
                 assert ctx.counters()[2] < 0.5 * ns
+
+
+def test_exact_leaping_flavour(ctx):
+    """Flavour 4 jumps over m steps at once: bits(x after m additions) = bits(x1) + (m-1)*(bits(x2)-bits(x1)) while
+    sign and exponent hold.  Must reproduce the step-by-step accumulation bit for bit (frames AND sample counts)."""
+    n = 96
+    raw = np.zeros((n, n, n), dtype=np.uint16)
+    raw[40:56, 30:70, 44:60] = 3000
+    raw[10, 85, 20] = 2000
+    v = ob.precompute_gradient(ob.normalize_data(hr.raw_to_vec4(raw)))
+    tf = zero_prefix_tf(64, 2, top=0.05)
+    step, count = hr.stepping_params(n, n, n)
+    W, H = 72, 56
+    ctx.resize(W, H)
+    try:
+        ctx.set_kernel_flavour(4)
+        for cam in [dict(yaw=0.6, pitch=0.35), dict(yaw=2.2, pitch=-0.6, distance=0.9), dict(yaw=-1.3, pitch=1.1),
+                    dict(yaw=0.0, pitch=0.0, distance=3.0), dict(yaw=1.5707, pitch=0.0, distance=0.8)]:
+            for extra in (dict(), dict(clip_x=(0.1, 0.2)), dict(toggles=(1, 1, 0, 0), steps_count=count // 2)):
+                kw = dict(steps_count=count, step_size=step)
+                kw.update(cam)
+                kw.update(extra)
+                u = hr.make_uniforms(W, H, **kw)
+                for variant in (capi.BASIC, capi.LIGHT, capi.THREE_FILES):
+                    vols = [v] if variant != capi.THREE_FILES else [v, vt.dose_volume()]
+                    tfs = [tf] if variant != capi.THREE_FILES else [tf, vt.scene(capi.THREE_FILES, n=8)[1][1]]
+                    check(ctx, variant, u, vols, tfs, W, H)
+        vols, tfs = vt.scene(capi.VOLUME_MASK, n=40)
+        tfs[0] = zero_prefix_tf(64, 9)
+        s40, c40 = hr.stepping_params(40, 40, 40)
+        check(ctx, capi.VOLUME_MASK, hr.make_uniforms(W, H, steps_count=c40, step_size=s40), vols, tfs, W, H)
+    finally:
+        ctx.set_kernel_flavour(0)

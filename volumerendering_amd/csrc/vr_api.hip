@@ -38,6 +38,12 @@ struct vr_ctx {
     float2* vol_bricks[VR_MAX_VOLUMES] = {};  // per brick: (max density, max(r,g,b)) -- empty-space skipping
     float2* merged_bricks = nullptr;           // VOLUME_MASK: (CT density max, mask rgb max), rebuilt when stale
     bool merged_stale = true;
+    unsigned char* brick_dist = nullptr;       // distance field over the records in use; key below says for what
+    size_t dist_cap = 0;
+    const void* dist_records = nullptr;
+    unsigned long long dist_epoch = ~0ull;     // volume-change counter the field was built at
+    int dist_z = -2, dist_res = 0, dist_rgb = -1;
+    unsigned long long brick_epoch = 0;        // bumped whenever any brick table changes
     int tf_zero_prefix[VR_MAX_TFS] = {-1, -1};  // zero prefix of each opacity table, -1 if none / not finite
     bool tf_color_finite[VR_MAX_TFS] = {false, false};
     bool tf_opacity_finite[VR_MAX_TFS] = {false, false};
@@ -73,7 +79,7 @@ int fail(vr_ctx* c, int code, const std::string& msg)
         hipError_t e__ = (call);                                                                      \
         if (e__ != hipSuccess)                                                                        \
             return fail((c), e__ == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_HIP,                    \
-                        std::string(#call) + ": " + hipGetErrorString(e__));                          \
+                        std::string(#call) + " (vr_api.hip:" + std::to_string(__LINE__) + "): " + hipGetErrorString(e__));                          \
     } while (0)
 
 int refresh_bricks(vr_ctx* c, int slot);
@@ -123,22 +129,20 @@ int alloc_frame(vr_ctx* c)
 }
 
 template <int V>
-void launch_variant(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
+void launch_variant(bool off32, bool leap, dim3 grid, hipStream_t s, const MarchParams& P)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
+#define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L>), grid, dim3(256), 0, s, P)
     if constexpr (kCanSkip) {
-        if (P.bricks) {
-            if (off32)
-                hipLaunchKernelGGL((march_kernel<V, true, true>), grid, dim3(256), 0, s, P);
-            else
-                hipLaunchKernelGGL((march_kernel<V, false, true>), grid, dim3(256), 0, s, P);
+        if (P.brick_dist) {
+            if (off32) { if (leap) VR_LAUNCH(true, true, true); else VR_LAUNCH(true, true, false); }
+            else { if (leap) VR_LAUNCH(false, true, true); else VR_LAUNCH(false, true, false); }
             return;
         }
     }
-    if (off32)
-        hipLaunchKernelGGL((march_kernel<V, true, false>), grid, dim3(256), 0, s, P);
-    else
-        hipLaunchKernelGGL((march_kernel<V, false, false>), grid, dim3(256), 0, s, P);
+    if (off32) VR_LAUNCH(true, false, false);
+    else VR_LAUNCH(false, false, false);
+#undef VR_LAUNCH
 }
 
 bool all_finite(const float* v, int n)
@@ -236,6 +240,32 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             P.bricks = c->merged_bricks;
             P.use_rgb = 1;
         }
+        // distance field over the inert bricks (Chebyshev distance to the nearest active brick), rebuilt when the
+        // records, the zero prefix or the table resolution changed since it was last built
+        const int nb = P.bnx * P.bny * P.bnz;
+        if (c->dist_records != (const void*)P.bricks || c->dist_epoch != c->brick_epoch || c->dist_z != P.tf_zero_prefix ||
+            c->dist_res != c->tf[0].res_o || c->dist_rgb != P.use_rgb || !c->brick_dist) {
+            if ((size_t)nb > c->dist_cap) {
+                if (c->brick_dist) (void)hipFree(c->brick_dist);
+                c->brick_dist = nullptr;
+                c->dist_cap = 0;
+                VR_HIP(c, hipMalloc(&c->brick_dist, (size_t)nb));
+                c->dist_cap = (size_t)nb;
+            }
+            const dim3 g((unsigned)((nb + 255) / 256)), b(256);
+            hipLaunchKernelGGL(brick_active_kernel, g, b, 0, s, P.bricks, c->brick_dist, nb, P.use_rgb, P.tf_zero_prefix,
+                               c->tf[0].res_o);
+            for (int k = 1; k < kDistMax; ++k)
+                hipLaunchKernelGGL(brick_dist_pass_kernel, g, b, 0, s, c->brick_dist, P.bnx, P.bny, P.bnz, k);
+            hipLaunchKernelGGL(brick_dist_cap_kernel, g, b, 0, s, c->brick_dist, nb);
+            VR_HIP(c, hipGetLastError());
+            c->dist_records = (const void*)P.bricks;
+            c->dist_epoch = c->brick_epoch;
+            c->dist_z = P.tf_zero_prefix;
+            c->dist_res = c->tf[0].res_o;
+            c->dist_rgb = P.use_rgb;
+        }
+        P.brick_dist = c->brick_dist;
     }
 
     if (packed && !out) {
@@ -266,7 +296,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
         const bool wtb = (c->flavour == 2 || c->flavour == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
         if (wtb) {  // same grid as the default kernel
-            if (P.bricks) {
+            if (P.brick_dist) {
                 if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, P);
                 else hipLaunchKernelGGL((march_wtb_light_kernel<false, true>), grid, dim3(256), 0, s, P);
             } else {
@@ -275,12 +305,12 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             }
         } else
         switch (variant) {
-        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, grid, s, P); break;
-        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, grid, s, P); break;
-        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, grid, s, P); break;
-        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, grid, s, P); break;
-        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, grid, s, P); break;
-        default: launch_variant<V_TF_CALIB>(off32, grid, s, P); break;
+        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, c->flavour == 4, grid, s, P); break;
+        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, c->flavour == 4, grid, s, P); break;
+        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, c->flavour == 4, grid, s, P); break;
+        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, c->flavour == 4, grid, s, P); break;
+        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, c->flavour == 4, grid, s, P); break;
+        default: launch_variant<V_TF_CALIB>(off32, c->flavour == 4, grid, s, P); break;
         }
         VR_HIP(c, hipGetLastError());
         if (record_events) {
@@ -307,6 +337,7 @@ int refresh_bricks(vr_ctx* c, int slot)
     if (c->vol_bricks[slot]) (void)hipFree(c->vol_bricks[slot]);
     c->vol_bricks[slot] = nullptr;
     c->merged_stale = true;
+    ++c->brick_epoch;
     const int bnx = (v.nx + 7) >> kBrickShift, bny = (v.ny + 7) >> kBrickShift, bnz = (v.nz + 7) >> kBrickShift;
     const size_t nbricks = (size_t)bnx * bny * bnz;
     VR_HIP(c, hipMalloc(&c->vol_bricks[slot], nbricks * sizeof(float2)));
@@ -507,6 +538,7 @@ void vr_destroy(vr_ctx* c)
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
         if (c->vol_bricks[i]) (void)hipFree(c->vol_bricks[i]);
     if (c->merged_bricks) (void)hipFree(c->merged_bricks);
+    if (c->brick_dist) (void)hipFree(c->brick_dist);
     for (int i = 0; i < VR_MAX_TFS; ++i) {
         if (c->tf_opacity[i]) (void)hipFree(c->tf_opacity[i]);
         if (c->tf_color[i]) (void)hipFree(c->tf_color[i]);
@@ -781,7 +813,7 @@ int vr_last_counters(vr_ctx* c, uint64_t out[3])
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 3) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 4) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

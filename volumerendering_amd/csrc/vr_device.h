@@ -10,6 +10,7 @@ constexpr int kTile = 64;        // multi-GPU ownership granule (pixels)
 constexpr int kBlockEdge = 16;   // one 256-thread workgroup = 16x16 pixels = four 8x8 wave packets
 constexpr int kBlocksPerTile = (kTile / kBlockEdge) * (kTile / kBlockEdge);
 constexpr int kBrickShift = 3;    // empty-space bricks: 8x8x8 base cells
+constexpr int kDistMax = 16;      // cap of the brick distance field (leaps of up to 15 bricks)
 
 struct DevVolume {
     const float4* data;  // reference layout: x fastest, (k*ny + j)*nx + i   (VolumeFile.cpp:306)
@@ -44,6 +45,8 @@ struct MarchParams {
     const float2* bricks;    // nullptr = disabled; per brick: x = max of vol[skip_vol].a, y = max(r,g,b) of the mask
                              // (y is filled from vol[0]'s bricks for VOLUME_MASK and is 0 otherwise)
     int use_rgb;             // VOLUME_MASK: a brick is inert only if its mask record y <= 0
+    const unsigned char* brick_dist;  // per brick: 0 = active; k >= 1 = inert and every brick within Chebyshev
+                                      // distance k-1 is inert too (capped); rebuilt when the volume / opacity table change
     int skip_vol;            // which volume carries the density that drives the opacity (0, or 2 for VOLUME_MASK)
     int bnx, bny, bnz;       // bricks per axis
     float bsx, bsy, bsz;     // n/8 per axis of vol[skip_vol] (exact in f32)

@@ -447,7 +447,65 @@ __device__ __forceinline__ bool brick_inert(const MarchParams& P, float2 rec)
     return floorf(rec.x * (float)P.tf[0].res_o - 0.5f) + 2.0f <= (float)P.tf_zero_prefix;
 }
 
-template <int V, bool OFF32, bool SKIP>
+// ---- exact empty-space leaping -----------------------------------------------------------------------------
+// p advances by one ROUNDED addition of `s` per step.  While p keeps its sign and binary exponent its ulp U is
+// constant, p = n*U and s = (k + f)*U with |f| <= 1/2, so every addition moves p by the same whole number of ulps
+// (k, or from the second addition on k or k+1 in the exact-tie case f = 1/2, where round-to-even makes the result
+// even and the increment constant afterwards).  Hence, with x1 = fl(x + s) and x2 = fl(x1 + s),
+//      bits(x after m additions) = bits(x1) + (m - 1) * (bits(x2) - bits(x1)),        m >= 1,
+// provided x, x1, x2 and the result share sign and exponent (the sequence is monotone, so the end points suffice).
+// That makes a jump over m steps O(1) and bit-identical to m single steps.  Returns false when the condition fails
+// (the caller then takes a single ordinary step).  leap_plan also returns how many steps fit before the binade edge.
+struct LeapCoord {
+    int b0, b1, d;  // bits of x and of x1 = fl(x+s); ulps per step from the second addition on
+    float mmax;     // largest m (as float, conservative) for which the result keeps x's sign and exponent
+};
+__device__ __forceinline__ LeapCoord leap_plan(float x, float s)
+{
+    const float x1 = x + s, x2 = x1 + s;
+    LeapCoord c;
+    c.b0 = __float_as_int(x);
+    c.b1 = __float_as_int(x1);
+    const int b2 = __float_as_int(x2);
+    c.d = b2 - c.b1;
+    // room, in ulps, between x1 and the edge of its binade in the direction the MAGNITUDE moves
+    const int mag1 = c.b1 & 0x7FFFFFFF, mag2 = b2 & 0x7FFFFFFF;
+    const int dm = mag2 - mag1;
+    const int room = dm > 0 ? (0x7FFFFF - (mag1 & 0x7FFFFF)) : (mag1 & 0x7FFFFF);
+    const bool same = (((c.b0 ^ c.b1) | (c.b0 ^ b2)) & (int)0xFF800000) == 0;  // x, x1, x2 in one binade
+    // m - 1 further increments of |dm| ulps must fit into `room`
+    c.mmax = !same ? 0.0f : (dm == 0 ? 1.0e9f : 1.0f + (float)room * (__builtin_amdgcn_rcpf((float)abs(dm)) * 0.999f));
+    return c;
+}
+__device__ __forceinline__ int leap_apply(const LeapCoord& c, int m, float& out)
+{
+    const int r = c.b1 + (m - 1) * c.d;
+    out = __int_as_float(r);
+    return (((c.b0 ^ r) & (int)0xFF800000) == 0) ? 1 : 0;  // final guard: sign and exponent unchanged
+}
+
+// Number of steps (>= 0) a ray at p certainly stays inside the cube of bricks within Chebyshev distance D-1 of its
+// own brick -- all of them inert by construction of the distance field.  Same conservative span arithmetic as the
+// brick definition: base-cell index floor(p*n - 0.5) in [8*lo, 8*(hi+1)), shrunk by 0.01 cell; edge bricks also own
+// the clamped cells beyond the volume (no bound there: the caller keeps the leap inside the clip range).
+__device__ __forceinline__ float leap_axis(float p, float s, float bs, int nb, int k, float inv_n)
+{
+    if (s == 0.0f) return 1.0e9f;
+    const int b = clampi((int)floorf(p * bs - 0.0625f), 0, nb - 1);
+    float room;
+    if (s > 0.0f) {
+        const int hi = b + k;  // last inert brick index in the direction of travel
+        if (hi >= nb - 1) return 1.0e9f;
+        room = ((float)((hi + 1) << kBrickShift) + 0.49f) * inv_n - p;
+    } else {
+        const int lo = b - k;
+        if (lo <= 0) return 1.0e9f;
+        room = p - ((float)(lo << kBrickShift) + 0.51f) * inv_n;
+    }
+    return room * (__builtin_amdgcn_rcpf(fabsf(s)) * 0.999f);  // approximate reciprocal, scaled down: never too large
+}
+
+template <int V, bool OFF32, bool SKIP, bool LEAP>
 __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
 {
     PixelSlot slot = map_pixel(P);
@@ -504,30 +562,65 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                     const float f = fminf(fminf(fx, fy), fminf(fz, 1.0e6f)) * 0.999f - 2.0f;
                     if (in0 && f > 0.0f) n_inside = (int)f;  // NaN / negative -> 0
                 }
-                // Empty-space test, software-pipelined and branch-free: every iteration loads the brick record of
-                // the NEXT position (the same rounded additions the advance performs, so it is the position the next
-                // iteration really has) and the record is consumed one iteration later.  With 64 rays per wavefront
-                // some lane enters a new brick almost every step; a load-and-wait inside a divergent branch would
-                // stall the whole wavefront each time, an unconditional load whose lanes hit the same one or two
-                // 64-byte lines does not.
-                float2 rec = make_float2(0.0f, 0.0f);
-                if constexpr (SKIP) rec = brick_record(P, brick_of(P, p));
-                for (int i = 0; i < P.steps_count; ++i) {
+                // Empty-space test, software-pipelined and branch-free: every iteration loads the distance-field byte
+                // of the NEXT position (the same rounded additions the advance performs, so it is the position the next
+                // iteration really has) and consumes it one iteration later.  With 64 rays per wavefront some lane
+                // enters a new brick almost every step; a load-and-wait inside a divergent branch would stall the whole
+                // wavefront each time, an unconditional load whose lanes hit the same one or two lines does not.
+                unsigned D = 0;  // 0: active brick; k >= 1: inert, and so is everything within k-1 bricks
+                if constexpr (SKIP) D = P.brick_dist[brick_of(P, p)];
+                const int lim = min(n_inside, P.steps_count);  // leaps stay inside the provably-in-box prefix
+                for (int i = 0; i < P.steps_count;) {
                     bool inb = true;
                     if (i >= n_inside)
                         inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
-                    const f3 pn = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
-                    float2 rec_next = rec;
-                    if constexpr (SKIP) rec_next = brick_record(P, brick_of(P, pn));
+                    f3 pn = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                    unsigned Dn = 0;
+                    if constexpr (SKIP) Dn = P.brick_dist[brick_of(P, pn)];
+                    int adv = 1;  // steps this iteration advances by
                     if (inb) {
-                        bool inert = false;
-                        if constexpr (SKIP) inert = brick_inert(P, rec);
-                        if (!inert) {
+                        if (!SKIP || D == 0) {
                             sample_and_blend<V, OFF32>(P, p, w, dst);
                             ++fetched;
+                            ++blends;
+                            if (!can_blend<V>(dst.w)) break;  // cut-off reached: no later iteration can blend
+                        } else {
+                            // identity blend(s): the reference executes them, nothing changes and nothing is fetched
+                            if constexpr (LEAP) {
+                                if (D >= 2 && i + 3 < lim) {
+                                    const DevVolume& v = P.vol[P.skip_vol];
+                                    const int k = (int)D - 1;
+                                    float mf = fminf(fminf(leap_axis(p.x, step.x, P.bsx, P.bnx, k, 1.0f / (float)v.nx),
+                                                           leap_axis(p.y, step.y, P.bsy, P.bny, k, 1.0f / (float)v.ny)),
+                                                     fminf(leap_axis(p.z, step.z, P.bsz, P.bnz, k, 1.0f / (float)v.nz), 255.0f));
+                                    // every coordinate also bounds the leap by its room to the edge of its binade
+                                    const LeapCoord cx = leap_plan(p.x, step.x), cy = leap_plan(p.y, step.y),
+                                                    cz = leap_plan(p.z, step.z);
+                                    mf = fminf(fminf(mf - 1.0f, cx.mmax), fminf(cy.mmax, cz.mmax));
+                                    LeapCoord wx = cx, wy = cy, wz = cz;
+                                    if constexpr (V != V_BASIC && V != V_TF_CALIB) {
+                                        wx = leap_plan(w.x, wstep.x);
+                                        wy = leap_plan(w.y, wstep.y);
+                                        wz = leap_plan(w.z, wstep.z);
+                                        mf = fminf(fminf(mf, wx.mmax), fminf(wy.mmax, wz.mmax));
+                                    }
+                                    const int m = min((int)mf, lim - i - 1);
+                                    if (m >= 3) {
+                                        f3 q, wq = w;
+                                        int ok = leap_apply(cx, m, q.x) & leap_apply(cy, m, q.y) & leap_apply(cz, m, q.z);
+                                        if constexpr (V != V_BASIC && V != V_TF_CALIB)
+                                            ok = ok & leap_apply(wx, m, wq.x) & leap_apply(wy, m, wq.y) & leap_apply(wz, m, wq.z);
+                                        if (ok) {  // all m steps are in-box identity blends: count them and land
+                                            adv = m;
+                                            pn = q;
+                                            if constexpr (V != V_BASIC && V != V_TF_CALIB) w = wq;
+                                            Dn = P.brick_dist[brick_of(P, pn)];
+                                        }
+                                    }
+                                }
+                            }
+                            blends += (unsigned)adv;
                         }
-                        ++blends;  // the reference's blend executes here; with opacity exactly 0 it is the identity
-                        if (!can_blend<V>(dst.w)) break;  // cut-off reached: no later iteration can blend
                     } else {
                         // p moves monotonically per component: once past the far bound it never returns
                         bool gone = (step.x >= 0.0f && p.x > bx1) || (step.x <= 0.0f && p.x < bx0) ||
@@ -536,8 +629,11 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                         if (gone) break;
                     }
                     p = pn;
-                    rec = rec_next;
-                    if constexpr (V != V_BASIC && V != V_TF_CALIB) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                    D = Dn;
+                    if (adv == 1) {
+                        if constexpr (V != V_BASIC && V != V_TF_CALIB) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                    }
+                    i += adv;
                 }
             }
         }
@@ -621,6 +717,45 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4*
     int r = t % world, n = t / world;
     size_t src = ((size_t)r * tiles_per_rank_max + n) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile);
     frame[(size_t)y * W + x] = gathered[src];
+}
+
+// ---- brick distance field (rebuilt when the volume or the opacity table changes) --------------------------------
+// pass 0: 0 for active bricks, 255 ("not reached yet") for inert ones
+__global__ void brick_active_kernel(const float2* __restrict__ rec, unsigned char* __restrict__ dist, int n, int use_rgb,
+                                    int zero_prefix, int res_o)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 r = rec[i];
+    bool inert;
+    if (use_rgb && !(r.y <= 0.0f)) inert = false;
+    else if (r.x <= 0.0f) inert = zero_prefix >= 0;
+    else inert = floorf(r.x * (float)res_o - 0.5f) + 2.0f <= (float)zero_prefix;
+    dist[i] = inert ? 255 : 0;
+}
+// pass k = 1 .. kDistMax-1: an unreached brick with a neighbour (26-neighbourhood) at distance k-1 is at distance k.
+// Neighbours written in the same pass carry k, never k-1, so the in-place update is race-free in effect.
+__global__ void brick_dist_pass_kernel(unsigned char* __restrict__ dist, int bnx, int bny, int bnz, int k)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bnx * bny * bnz || dist[i] != 255) return;
+    const int x = i % bnx, y = (i / bnx) % bny, z = i / (bnx * bny);
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int X = x + dx, Y = y + dy, Z = z + dz;
+                if (X < 0 || Y < 0 || Z < 0 || X >= bnx || Y >= bny || Z >= bnz) continue;
+                if (dist[(Z * bny + Y) * bnx + X] == (unsigned char)(k - 1)) {
+                    dist[i] = (unsigned char)k;
+                    return;
+                }
+            }
+}
+// final pass: bricks never reached are at least kDistMax away
+__global__ void brick_dist_cap_kernel(unsigned char* __restrict__ dist, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && dist[i] == 255) dist[i] = (unsigned char)kDistMax;
 }
 
 // VOLUME_MASK looks at two volumes on one grid: record = (max density of the CT, max(r,g,b) of the mask)
