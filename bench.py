@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flavour", type=int, default=0)
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
+    ap.add_argument("--exp-mode", type=int, default=0, help="experiment: fragmentMode 1-4 (ray set-up only)")
+    ap.add_argument("--exp-steps", type=int, default=-1, help="experiment: override stepsCount")
     args = ap.parse_args()
 
     import torch
@@ -157,6 +159,9 @@ def main():
     ctx = app.context()
     if args.flavour:
         ctx.set_kernel_flavour(args.flavour)
+    if args.exp_mode or args.exp_steps >= 0:  # experiments only: not the BASELINE workload any more
+        app.set_params(fragment_mode=args.exp_mode, steps_count=args.exp_steps)
+        app.OnUpdate()
     steps_count, step_size = app.stepping()
     stream = torch.cuda.current_stream().cuda_stream
 

@@ -196,9 +196,9 @@ int vr_download_tiles(vr_ctx* ctx, float* tiles_rgba, uint64_t* composited_sampl
 
 /* ---- instrumentation ------------------------------------------------------------------ */
 
-/* HIP-event time of the last render's march kernel and of the whole render call (ray set-up,
- * march, counters), in milliseconds; valid after a synchronous render or after the caller
- * synchronised the stream.  Replaces the FPS / frame-time read-out (Application.cpp:339-370).    */
+/* HIP-event time of the last synchronous render's (vr_render / vr_render_tiles) march kernel and of
+ * the whole render call, in milliseconds; VR_ERR_NOT_READY after an *_async render (those record only the
+ * kernel events vr_kernel_times reads).  Replaces the FPS / frame-time read-out (Application.cpp:339-370). */
 int vr_last_timing(vr_ctx* ctx, float* kernel_ms, float* total_ms);
 
 /* HIP-event durations (ms) of the march kernel for the most recent render calls, oldest first, recorded on
@@ -218,9 +218,11 @@ int vr_last_covered_pixels(vr_ctx* ctx, uint64_t* covered);
  * samples the exact empty-space test proved to be the identity).                                 */
 int vr_last_counters(vr_ctx* ctx, uint64_t out[3]);
 
-/* Kernel flavour for A/B measurements: 0 = default (best), 1 = no empty-space skipping, 2 = LDS wave tiles
+/* Kernel flavour for A/B measurements: 0 = default (best: exact empty-space skipping plus
+ * wave-uniform runs of plain additions through inert bricks), 1 = no empty-space skipping, 2 = LDS wave tiles
  * without skipping, 3 = LDS wave tiles with skipping (lit shader only; others fall back to 0 / 1), 4 = skipping
- * plus exact empty-space leaping (closed-form f32 accumulation over a brick distance field).  All
+ * plus closed-form leaping (f32 accumulation as integer arithmetic on the bit patterns), 5 = skipping alone,
+ * one step per iteration.  All
  * flavours are bit-identical in output and in the composited-sample count.                       */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 

@@ -335,8 +335,9 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
                 assert ctx.counters()[2] < 0.5 * ns
 
 
-def test_exact_leaping_flavour(ctx):
-    """Flavour 4 jumps over m steps at once: bits(x after m additions) = bits(x1) + (m-1)*(bits(x2)-bits(x1)) while
+@pytest.mark.parametrize("flavour", [4, 5])
+def test_exact_leaping_flavour(ctx, flavour):
+    """Flavour 5 lets a whole ray packet run through inert bricks with plain additions only.  Flavour 4 jumps over m steps at once: bits(x after m additions) = bits(x1) + (m-1)*(bits(x2)-bits(x1)) while
     sign and exponent hold.  Must reproduce the step-by-step accumulation bit for bit (frames AND sample counts)."""
     n = 96
     raw = np.zeros((n, n, n), dtype=np.uint16)
@@ -348,7 +349,7 @@ def test_exact_leaping_flavour(ctx):
     W, H = 72, 56
     ctx.resize(W, H)
     try:
-        ctx.set_kernel_flavour(4)
+        ctx.set_kernel_flavour(flavour)
         for cam in [dict(yaw=0.6, pitch=0.35), dict(yaw=2.2, pitch=-0.6, distance=0.9), dict(yaw=-1.3, pitch=1.1),
                     dict(yaw=0.0, pitch=0.0, distance=3.0), dict(yaw=1.5707, pitch=0.0, distance=0.8)]:
             for extra in (dict(), dict(clip_x=(0.1, 0.2)), dict(toggles=(1, 1, 0, 0), steps_count=count // 2)):

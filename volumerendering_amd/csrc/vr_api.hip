@@ -58,6 +58,11 @@ struct vr_ctx {
     int last_tiles = 0;         // tiles rendered by the last vr_render_tiles
     uint32_t* d_present = nullptr;
     unsigned long long* d_counters = nullptr;  // [3] composited, covered, fetched
+    unsigned long long* d_block_counts = nullptr;  // per-block partial sums of the last launch
+    size_t block_counts_cap = 0;               // in blocks
+    bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
+    int cnt_blocks = 0;
+    hipStream_t cnt_stream = nullptr;
     unsigned long long* h_counters = nullptr;  // pinned [3]
     Timing tm;
     KernelRing ring;
@@ -129,19 +134,26 @@ int alloc_frame(vr_ctx* c)
 }
 
 template <int V>
-void launch_variant(bool off32, bool leap, dim3 grid, hipStream_t s, const MarchParams& P)
+void launch_variant(bool off32, int leap, dim3 grid, hipStream_t s, const MarchParams& P)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
 #define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L>), grid, dim3(256), 0, s, P)
     if constexpr (kCanSkip) {
         if (P.brick_dist) {
-            if (off32) { if (leap) VR_LAUNCH(true, true, true); else VR_LAUNCH(true, true, false); }
-            else { if (leap) VR_LAUNCH(false, true, true); else VR_LAUNCH(false, true, false); }
+            if (off32) {
+                if (leap == 2) VR_LAUNCH(true, true, 2);
+                else if (leap == 1) VR_LAUNCH(true, true, 1);
+                else VR_LAUNCH(true, true, 0);
+            } else {
+                if (leap == 2) VR_LAUNCH(false, true, 2);
+                else if (leap == 1) VR_LAUNCH(false, true, 1);
+                else VR_LAUNCH(false, true, 0);
+            }
             return;
         }
     }
-    if (off32) VR_LAUNCH(true, false, false);
-    else VR_LAUNCH(false, false, false);
+    if (off32) VR_LAUNCH(true, false, 0);
+    else VR_LAUNCH(false, false, 0);
 #undef VR_LAUNCH
 }
 
@@ -154,7 +166,7 @@ bool all_finite(const float* v, int n)
 
 // Enqueue one render on `s`.  out == nullptr -> ctx-owned buffer.
 int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, float4* out, hipStream_t s,
-                   bool record_events)
+                   bool frame_events)
 {
     if (variant < 0 || variant >= VR_VARIANT_COUNT) return fail(c, VR_ERR_INVALID_ARG, "vr_render: bad variant");
     if (world < 1 || rank < 0 || rank >= world) return fail(c, VR_ERR_INVALID_ARG, "vr_render: bad rank/world");
@@ -200,7 +212,6 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     P.n_tiles = tile_count(c, rank, world);
     P.packed = packed ? 1 : 0;
     P.n_blocks = P.n_tiles * kBlocksPerTile;
-    P.counters = c->d_counters;
     // exact empty-space skipping: only for the shaders whose opacity is the CT table value alone, only when a
     // zero-opacity sample is provably the identity (finite colour table and light), and unless flavour 1 asks
     // for the plain kernel
@@ -284,15 +295,20 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     P.out = out;
     c->last_tiles = packed ? P.n_tiles : 0;
 
-    if (record_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
-    VR_HIP(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), s));
+    if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
     if (P.n_blocks > 0) {
         dim3 grid((unsigned)((P.n_tiles + 7) / 8 * 8 * kBlocksPerTile));  // whole tiles per XCD, see map_pixel
-        const int slot = (int)(c->ring.head % kRing);
-        if (record_events) {
-            VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
-            VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
+        if (grid.x > c->block_counts_cap) {
+            if (c->d_block_counts) (void)hipFree(c->d_block_counts);
+            c->d_block_counts = nullptr;
+            c->block_counts_cap = 0;
+            VR_HIP(c, hipMalloc(&c->d_block_counts, (size_t)grid.x * 3 * sizeof(unsigned long long)));
+            c->block_counts_cap = grid.x;
         }
+        P.block_counts = c->d_block_counts;
+        const int slot = (int)(c->ring.head % kRing);
+        if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
+        VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
         // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
         const bool wtb = (c->flavour == 2 || c->flavour == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
         if (wtb) {  // same grid as the default kernel
@@ -305,28 +321,49 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             }
         } else
         switch (variant) {
-        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, c->flavour == 4, grid, s, P); break;
-        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, c->flavour == 4, grid, s, P); break;
-        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, c->flavour == 4, grid, s, P); break;
-        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, c->flavour == 4, grid, s, P); break;
-        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, c->flavour == 4, grid, s, P); break;
-        default: launch_variant<V_TF_CALIB>(off32, c->flavour == 4, grid, s, P); break;
+        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
+        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
+        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
+        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
+        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
+        default: launch_variant<V_TF_CALIB>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
         }
         VR_HIP(c, hipGetLastError());
-        if (record_events) {
-            VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
+        VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
+        if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
+        ++c->ring.head;
+        c->cnt_blocks = (int)grid.x;
+    } else {
+        c->cnt_blocks = 0;
+        if (frame_events) {
+            VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
             VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
-            ++c->ring.head;
         }
-    } else if (record_events) {
-        VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
-        VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
     }
-    VR_HIP(c, hipMemcpyAsync(c->h_counters, c->d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    if (record_events) {
-        VR_HIP(c, hipEventRecord(c->tm.ev_end, s));
-        c->tm.valid = true;
+    // the per-block counts are summed and copied to the host when somebody asks for them (fetch_counters)
+    c->cnt_pending = true;
+    c->cnt_stream = s;
+    if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_end, s));
+    c->tm.valid = frame_events;
+    return VR_OK;
+}
+
+// Sums the per-block counts of the last launch into h_counters (blocks until that launch has finished).
+int fetch_counters(vr_ctx* c)
+{
+    if (!c->cnt_pending) return VR_OK;
+    VR_HIP(c, hipSetDevice(c->device));
+    if (c->cnt_blocks > 0) {
+        hipLaunchKernelGGL(sum_block_counts_kernel, dim3(1), dim3(256), 0, c->cnt_stream, c->d_block_counts, c->cnt_blocks,
+                           c->d_counters);
+        VR_HIP(c, hipGetLastError());
+        VR_HIP(c, hipMemcpyAsync(c->h_counters, c->d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                 c->cnt_stream));
+        VR_HIP(c, hipStreamSynchronize(c->cnt_stream));
+    } else {
+        c->h_counters[0] = c->h_counters[1] = c->h_counters[2] = 0;
     }
+    c->cnt_pending = false;
     return VR_OK;
 }
 
@@ -547,6 +584,7 @@ void vr_destroy(vr_ctx* c)
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_present) (void)hipFree(c->d_present);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_block_counts) (void)hipFree(c->d_block_counts);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (int i = 0; i < kRing; ++i) {
         if (c->ring.k0[i]) (void)hipEventDestroy(c->ring.k0[i]);
@@ -675,7 +713,7 @@ int vr_render(vr_ctx* c, int variant)
     int rc = enqueue_render(c, variant, 0, 1, false, nullptr, c->stream, true);
     if (rc != VR_OK) return rc;
     VR_HIP(c, hipStreamSynchronize(c->stream));
-    return VR_OK;
+    return fetch_counters(c);
 }
 
 int vr_tile_count(const vr_ctx* c, int rank, int world)
@@ -690,21 +728,21 @@ int vr_render_tiles(vr_ctx* c, int variant, int rank, int world)
     int rc = enqueue_render(c, variant, rank, world, true, nullptr, c->stream, true);
     if (rc != VR_OK) return rc;
     VR_HIP(c, hipStreamSynchronize(c->stream));
-    return VR_OK;
+    return fetch_counters(c);
 }
 
 int vr_render_async(vr_ctx* c, int variant, void* d_frame, void* stream)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    return enqueue_render(c, variant, 0, 1, false, (float4*)d_frame, s, true);
+    return enqueue_render(c, variant, 0, 1, false, (float4*)d_frame, s, false);
 }
 
 int vr_render_tiles_async(vr_ctx* c, int variant, int rank, int world, void* d_tiles, void* stream)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    return enqueue_render(c, variant, rank, world, true, (float4*)d_tiles, s, true);
+    return enqueue_render(c, variant, rank, world, true, (float4*)d_tiles, s, false);
 }
 
 int vr_unpack_tiles_async(vr_ctx* c, const void* d_gathered, int world, void* d_frame, void* stream)
@@ -736,7 +774,11 @@ int vr_download(vr_ctx* c, float* frag_rgba, uint8_t* present_bgra8, uint64_t* c
         VR_HIP(c, hipStreamSynchronize(c->stream));
         VR_HIP(c, hipMemcpy(present_bgra8, c->d_present, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
-    if (composited_samples) *composited_samples = c->h_counters[0];
+    if (composited_samples) {
+        int rc = fetch_counters(c);
+        if (rc != VR_OK) return rc;
+        *composited_samples = c->h_counters[0];
+    }
     return VR_OK;
 }
 
@@ -748,14 +790,18 @@ int vr_download_tiles(vr_ctx* c, float* tiles_rgba, uint64_t* composited_samples
     if (tiles_rgba && c->last_tiles > 0)
         VR_HIP(c, hipMemcpy(tiles_rgba, c->d_tiles, (size_t)c->last_tiles * kTile * kTile * sizeof(float4),
                             hipMemcpyDeviceToHost));
-    if (composited_samples) *composited_samples = c->h_counters[0];
+    if (composited_samples) {
+        int rc = fetch_counters(c);
+        if (rc != VR_OK) return rc;
+        *composited_samples = c->h_counters[0];
+    }
     return VR_OK;
 }
 
 int vr_last_timing(vr_ctx* c, float* kernel_ms, float* total_ms)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (!c->tm.valid) return fail(c, VR_ERR_NOT_READY, "vr_last_timing: nothing rendered yet");
+    if (!c->tm.valid) return fail(c, VR_ERR_NOT_READY, "vr_last_timing: no vr_render / vr_render_tiles since the context was created or an *_async call");
     VR_HIP(c, hipSetDevice(c->device));
     VR_HIP(c, hipEventSynchronize(c->tm.ev_end));
     float k = 0.0f, t = 0.0f;
@@ -795,6 +841,8 @@ int vr_last_covered_pixels(vr_ctx* c, uint64_t* covered)
     if (!c || !covered) return VR_ERR_INVALID_ARG;
     VR_HIP(c, hipSetDevice(c->device));
     VR_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = fetch_counters(c);
+    if (rc != VR_OK) return rc;
     *covered = c->h_counters[1];
     return VR_OK;
 }
@@ -804,6 +852,8 @@ int vr_last_counters(vr_ctx* c, uint64_t out[3])
     if (!c || !out) return VR_ERR_INVALID_ARG;
     VR_HIP(c, hipSetDevice(c->device));
     VR_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = fetch_counters(c);
+    if (rc != VR_OK) return rc;
     out[0] = c->h_counters[0];
     out[1] = c->h_counters[1];
     out[2] = c->h_counters[2];
@@ -813,7 +863,7 @@ int vr_last_counters(vr_ctx* c, uint64_t out[3])
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 4) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 5) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

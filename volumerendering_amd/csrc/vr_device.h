@@ -52,7 +52,7 @@ struct MarchParams {
     float bsx, bsy, bsz;     // n/8 per axis of vol[skip_vol] (exact in f32)
     int tf_zero_prefix;      // largest Z with opacity[0..Z] == 0 exactly (-1: none)
     float4* out;
-    unsigned long long* counters;  // [0] composited samples, [1] covered pixels, [2] samples actually fetched
+    unsigned long long* block_counts;  // [gridDim.x][3]: composited samples, covered pixels, samples fetched
 };
 
 }  // namespace vr

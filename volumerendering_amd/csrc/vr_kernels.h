@@ -447,6 +447,34 @@ __device__ __forceinline__ bool brick_inert(const MarchParams& P, float2 rec)
     return floorf(rec.x * (float)P.tf[0].res_o - 0.5f) + 2.0f <= (float)P.tf_zero_prefix;
 }
 
+// Per-block sums of (composited samples, covered pixels, fetched samples): plain stores, no atomics.  (One atomic
+// triple per wavefront on three shared addresses -- ~37 k device-scope atomics per 1080p frame -- serialised at the
+// memory side and cost 0.3 ms per frame.)  sum_block_counts_kernel adds the blocks up.  Every thread of the block
+// must call this (it contains a barrier).
+__device__ __forceinline__ void store_block_counts(const MarchParams& P, unsigned blends, unsigned covered, unsigned fetched)
+{
+    __shared__ unsigned long long part[4][2];
+    unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
+    unsigned long long fetched_cnt = fetched;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        packed_cnt += __shfl_down(packed_cnt, off, 64);
+        fetched_cnt += __shfl_down(fetched_cnt, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6][0] = packed_cnt;
+        part[threadIdx.x >> 6][1] = fetched_cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long pc = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+        unsigned long long* o = P.block_counts + (size_t)blockIdx.x * 3;
+        o[0] = pc & ((1ull << 40) - 1);
+        o[1] = pc >> 40;
+        o[2] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+    }
+}
+
 // ---- exact empty-space leaping -----------------------------------------------------------------------------
 // p advances by one ROUNDED addition of `s` per step.  While p keeps its sign and binary exponent its ulp U is
 // constant, p = n*U and s = (k + f)*U with |f| <= 1/2, so every addition moves p by the same whole number of ulps
@@ -505,7 +533,7 @@ __device__ __forceinline__ float leap_axis(float p, float s, float bs, int nb, i
     return room * (__builtin_amdgcn_rcpf(fabsf(s)) * 0.999f);  // approximate reciprocal, scaled down: never too large
 }
 
-template <int V, bool OFF32, bool SKIP, bool LEAP>
+template <int V, bool OFF32, bool SKIP, int LEAP>
 __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
 {
     PixelSlot slot = map_pixel(P);
@@ -570,7 +598,41 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                 unsigned D = 0;  // 0: active brick; k >= 1: inert, and so is everything within k-1 bricks
                 if constexpr (SKIP) D = P.brick_dist[brick_of(P, p)];
                 const int lim = min(n_inside, P.steps_count);  // leaps stay inside the provably-in-box prefix
+                // LEAP == 2: steps a ray at distance-field value D can take while it certainly stays within D-1 bricks
+                // of its brick on every axis = (D - 1 - 1/16) / (largest per-step move in brick units), 0.1 % short
+                float leap_c = 0.0f;
+                if constexpr (LEAP == 2) {
+                    const float vmax = fmaxf(fmaxf(fabsf(step.x) * P.bsx, fabsf(step.y) * P.bsy), fabsf(step.z) * P.bsz);
+                    leap_c = 0.999f / vmax;  // vmax 0 -> inf (capped below), NaN -> n_inside is 0 and nothing leaps
+                }
                 for (int i = 0; i < P.steps_count;) {
+                    if constexpr (LEAP == 2) {
+                        // Wave-uniform run of identity steps: when EVERY ray of the packet that is still marching sits
+                        // at least 4 safe steps inside inert bricks, all of them take the same number of plain rounded
+                        // additions back to back (nothing else per step), then look their brick up again.  The rays
+                        // of a packet stay at one step index, so their samples keep sharing cache lines.
+                        int m = 0;
+                        if (D >= 2) m = min((int)fminf(((float)D - 1.0625f) * leap_c, 64.0f), lim - i - 1);
+                        if (__ballot(m < 4) == 0) {
+                            int mw = 4;
+                            if (__ballot(m < 8) == 0) {
+                                mw = 8;
+                                if (__ballot(m < 16) == 0) {
+                                    mw = 16;
+                                    if (__ballot(m < 32) == 0) mw = __ballot(m < 64) == 0 ? 64 : 32;
+                                }
+                            }
+                            for (int k = 0; k < mw; ++k) {
+                                p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                                if constexpr (V != V_BASIC && V != V_TF_CALIB)
+                                    w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                            }
+                            i += mw;
+                            blends += (unsigned)mw;
+                            D = P.brick_dist[brick_of(P, p)];
+                            continue;
+                        }
+                    }
                     bool inb = true;
                     if (i >= n_inside)
                         inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
@@ -586,7 +648,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                             if (!can_blend<V>(dst.w)) break;  // cut-off reached: no later iteration can blend
                         } else {
                             // identity blend(s): the reference executes them, nothing changes and nothing is fetched
-                            if constexpr (LEAP) {
+                            if constexpr (LEAP == 1) {
                                 if (D >= 2 && i + 3 < lim) {
                                     const DevVolume& v = P.vol[P.skip_vol];
                                     const int k = (int)D - 1;
@@ -642,18 +704,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
     // packed-tile launches write every slot of an owned tile (pixels outside the viewport = 0)
     if (slot.active || (P.packed && slot.in_launch)) P.out[slot.out_index] = dst;
 
-    // counters: wave reduction, one atomic pair per wave
-    unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) packed_cnt += __shfl_down(packed_cnt, off, 64);
-    unsigned long long fetched_cnt = fetched;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) fetched_cnt += __shfl_down(fetched_cnt, off, 64);
-    if ((threadIdx.x & 63) == 0 && packed_cnt != 0) {
-        atomicAdd(&P.counters[0], packed_cnt & ((1ull << 40) - 1));
-        atomicAdd(&P.counters[1], packed_cnt >> 40);
-        if (fetched_cnt) atomicAdd(&P.counters[2], fetched_cnt);
-    }
+    store_block_counts(P, blends, covered, fetched);
 }
 
 // One wavefront per brick: maximum of .a over the voxels [8b, min(8b+8, n-1)]^3 (NaN if any voxel is NaN).
@@ -717,6 +768,32 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4*
     int r = t % world, n = t / world;
     size_t src = ((size_t)r * tiles_per_rank_max + n) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile);
     frame[(size_t)y * W + x] = gathered[src];
+}
+
+// One block: adds the per-block counts of the last march launch up (out[0..2]).
+__global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned long long* __restrict__ in, int n_blocks,
+                                                               unsigned long long* __restrict__ out)
+{
+    __shared__ unsigned long long part[4][3];
+    unsigned long long a = 0, b = 0, f = 0;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        a += in[(size_t)i * 3];
+        b += in[(size_t)i * 3 + 1];
+        f += in[(size_t)i * 3 + 2];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+        f += __shfl_down(f, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6][0] = a;
+        part[threadIdx.x >> 6][1] = b;
+        part[threadIdx.x >> 6][2] = f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) out[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
 // ---- brick distance field (rebuilt when the volume or the opacity table changes) --------------------------------

@@ -259,18 +259,7 @@ __global__ __launch_bounds__(256) void march_wtb_light_kernel(const MarchParams 
 
     if (active || (P.packed && in_launch)) P.out[out_index] = dst;
 
-    unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
-    unsigned long long fetched_cnt = fetched;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        packed_cnt += __shfl_down(packed_cnt, off, 64);
-        fetched_cnt += __shfl_down(fetched_cnt, off, 64);
-    }
-    if (lane == 0 && packed_cnt != 0) {
-        atomicAdd(&P.counters[0], packed_cnt & ((1ull << 40) - 1));
-        atomicAdd(&P.counters[1], packed_cnt >> 40);
-        if (fetched_cnt) atomicAdd(&P.counters[2], fetched_cnt);
-    }
+    store_block_counts(P, blends, covered, fetched);
 }
 
 }  // namespace vr
