@@ -218,6 +218,11 @@ int vr_last_covered_pixels(vr_ctx* ctx, uint64_t* covered);
  * samples the exact empty-space test proved to be the identity).                                 */
 int vr_last_counters(vr_ctx* ctx, uint64_t out[3]);
 
+/* Per-workgroup trace of the last march launch, for load-balance analysis: 6 words per workgroup
+ * {composited samples, covered pixels, fetched samples, start, end (100 MHz device clock), HW_ID | XCC_ID << 32},
+ * in blockIdx order.  Writes min(capacity, n) records and returns n (the number of workgroups launched).      */
+int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
+
 /* Kernel flavour for A/B measurements: 0 = default (best: exact empty-space skipping plus
  * wave-uniform runs of plain additions through inert bricks), 1 = no empty-space skipping, 2 = LDS wave tiles
  * without skipping, 3 = LDS wave tiles with skipping (lit shader only; others fall back to 0 / 1), 4 = skipping

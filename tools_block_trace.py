@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Load-balance analysis of one march launch from the per-workgroup trace (vr_last_block_trace):
+
+    python tools_block_trace.py [bench.py scene args: --workload C3 --tf thin --flavour N] > gpurun_out/trace.txt
+
+Prints, per XCD and for the whole device: the span (first start .. last end), the summed workgroup time, the
+time-averaged number of resident workgroups, and how the workgroup durations are distributed."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--tf", default="default")
+    ap.add_argument("--flavour", type=int, default=0)
+    a = ap.parse_args()
+    import bench
+    from volumerendering_amd import capi, host, synth
+    n, W, H, vname = bench.WORKLOADS[a.workload]
+    app = host.Application(W, H, 0)
+    variant, vols = bench.build_scene(app, host, synth, capi, a.workload, a.tf)
+    ctx = app.context()
+    ctx.set_kernel_flavour(a.flavour)
+    for _ in range(3):
+        app.OnRender()
+    tr = ctx.block_trace().astype(np.int64)
+    t0, t1 = tr[:, 3], tr[:, 4]
+    xcc = (tr[:, 5] >> 32) & 0xF
+    hw = tr[:, 5] & 0xFFFFFFFF
+    cu = (hw >> 8) & 0xF
+    se = (hw >> 13) & 0x7
+    base = t0.min()
+    span = (t1.max() - base) / 100.0  # us
+    dur = (t1 - t0) / 100.0
+    print(f"workgroups {len(tr)}  device span {span:.1f} us  sum of workgroup time {dur.sum():.0f} us  "
+          f"mean resident workgroups {dur.sum() / span:.1f}")
+    print(f"duration us: median {np.median(dur):.1f}  p90 {np.percentile(dur, 90):.1f}  p99 {np.percentile(dur, 99):.1f}  max {dur.max():.1f}")
+    heavy = tr[:, 2] > 0
+    print(f"workgroups that fetched samples: {heavy.sum()}  their mean duration {dur[heavy].mean():.1f} us, "
+          f"mean fetched {tr[heavy, 2].mean():.0f}, ns per fetched sample-lane {1e3 * dur[heavy].sum() / tr[heavy, 2].sum():.3f}")
+    for x in sorted(set(xcc.tolist())):
+        m = xcc == x
+        print(f"  XCD {x}: workgroups {m.sum():5d}  first start {(t0[m].min() - base) / 100.0:7.1f}  last end {(t1[m].max() - base) / 100.0:7.1f} us  "
+              f"busy {dur[m].sum():9.0f} us  fetched {tr[m, 2].sum():10d}  composited {tr[m, 0].sum():11d}  CUs seen {len(set(zip(se[m].tolist(), cu[m].tolist())))}")
+    order = np.argsort(-dur)[:12]
+    print("longest workgroups: duration us / start us / fetched / composited / XCD / tile ordinal")
+    for i in order:
+        tile = (i & 7) + 8 * ((i >> 3) // 16)
+        print(f"   {dur[i]:7.1f} {(t0[i] - base) / 100.0:7.1f} {tr[i, 2]:8d} {tr[i, 0]:8d}   {xcc[i]}  {tile}")
+    # residency over time (20 bins)
+    edges = np.linspace(0, span, 21)
+    res = []
+    for i in range(20):
+        lo, hi = edges[i], edges[i + 1]
+        ov = np.clip(np.minimum((t1 - base) / 100.0, hi) - np.maximum((t0 - base) / 100.0, lo), 0, None)
+        res.append(ov.sum() / (hi - lo))
+    print("resident workgroups per 5 % of the span:", " ".join(f"{r:.0f}" for r in res))
+
+
+if __name__ == "__main__":
+    main()

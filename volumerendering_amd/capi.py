@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "vr_volume_upload_device", "vr_volume_upload_raw16", "vr_volume_upload_raw32", "vr_volume_normalize",
     "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
-    "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour",
+    "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace",
 ]
 
 
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.vr_frame_device_ptr.restype = vp
     lib.vr_last_covered_pixels.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.vr_last_counters.argtypes = [vp, C.POINTER(C.c_uint64 * 3)]
+    lib.vr_last_block_trace.argtypes = [vp, C.c_void_p, C.c_int]
     lib.vr_set_kernel_flavour.argtypes = [vp, i32]
     _lib = lib
     return lib
@@ -251,6 +252,17 @@ class Context:
         out = (C.c_uint64 * 3)()
         self._chk(self.lib.vr_last_counters(self.h, C.byref(out)))
         return int(out[0]), int(out[1]), int(out[2])
+
+    def block_trace(self):
+        """(n, 6) uint64 array, one row per workgroup of the last march launch: composited, covered, fetched,
+        start, end (100 MHz device clock), HW_ID | XCC_ID << 32."""
+        n = self.lib.vr_last_block_trace(self.h, None, 0)
+        if n < 0:
+            self._chk(n)
+        out = np.zeros((max(n, 0), 6), dtype=np.uint64)
+        if n > 0:
+            self._chk(min(0, self.lib.vr_last_block_trace(self.h, out.ctypes.data_as(C.c_void_p), n)))
+        return out
 
     def frame_device_ptr(self) -> int:
         return int(self.lib.vr_frame_device_ptr(self.h) or 0)

@@ -6,6 +6,7 @@
 #include "vr_wtb.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -67,6 +68,9 @@ struct vr_ctx {
     Timing tm;
     KernelRing ring;
     int flavour = 0;
+    int waves_per_block = 4;  // 1 or 4 (experiment knob VR_EXP_WAVES_PER_BLOCK)
+    int only_tile = -1;       // experiment knob VR_EXP_ONLY_TILE
+    int prio_mode = 0;        // experiment knob VR_EXP_PRIO
     std::string err;
 };
 
@@ -134,18 +138,20 @@ int alloc_frame(vr_ctx* c)
 }
 
 template <int V>
-void launch_variant(bool off32, int leap, dim3 grid, hipStream_t s, const MarchParams& P)
+void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchParams& P)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
-#define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L>), grid, dim3(256), 0, s, P)
+#define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L>), grid, block, 0, s, P)
     if constexpr (kCanSkip) {
         if (P.brick_dist) {
             if (off32) {
                 if (leap == 2) VR_LAUNCH(true, true, 2);
+                else if (leap == 3) VR_LAUNCH(true, true, 3);
                 else if (leap == 1) VR_LAUNCH(true, true, 1);
                 else VR_LAUNCH(true, true, 0);
             } else {
                 if (leap == 2) VR_LAUNCH(false, true, 2);
+                else if (leap == 3) VR_LAUNCH(false, true, 3);
                 else if (leap == 1) VR_LAUNCH(false, true, 1);
                 else VR_LAUNCH(false, true, 0);
             }
@@ -212,6 +218,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     P.n_tiles = tile_count(c, rank, world);
     P.packed = packed ? 1 : 0;
     P.n_blocks = P.n_tiles * kBlocksPerTile;
+    P.only_tile = c->only_tile;
+    P.prio_mode = c->prio_mode;
     // exact empty-space skipping: only for the shaders whose opacity is the CT table value alone, only when a
     // zero-opacity sample is provably the identity (finite colour table and light), and unless flavour 1 asks
     // for the plain kernel
@@ -297,21 +305,23 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
 
     if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
     if (P.n_blocks > 0) {
-        dim3 grid((unsigned)((P.n_tiles + 7) / 8 * 8 * kBlocksPerTile));  // whole tiles per XCD, see map_pixel
+        // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
+        const bool wtb = (c->flavour == 2 || c->flavour == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
+        const int wpb = wtb ? 4 : c->waves_per_block;
+        dim3 block((unsigned)(64 * wpb));
+        dim3 grid((unsigned)((P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // whole tiles per XCD, see map_pixel
         if (grid.x > c->block_counts_cap) {
             if (c->d_block_counts) (void)hipFree(c->d_block_counts);
             c->d_block_counts = nullptr;
             c->block_counts_cap = 0;
-            VR_HIP(c, hipMalloc(&c->d_block_counts, (size_t)grid.x * 3 * sizeof(unsigned long long)));
+            VR_HIP(c, hipMalloc(&c->d_block_counts, (size_t)grid.x * kBlockRecord * sizeof(unsigned long long)));
             c->block_counts_cap = grid.x;
         }
         P.block_counts = c->d_block_counts;
         const int slot = (int)(c->ring.head % kRing);
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
         VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
-        // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
-        const bool wtb = (c->flavour == 2 || c->flavour == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
-        if (wtb) {  // same grid as the default kernel
+        if (wtb) {
             if (P.brick_dist) {
                 if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, P);
                 else hipLaunchKernelGGL((march_wtb_light_kernel<false, true>), grid, dim3(256), 0, s, P);
@@ -321,12 +331,12 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             }
         } else
         switch (variant) {
-        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
-        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
-        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
-        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
-        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
-        default: launch_variant<V_TF_CALIB>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : 2), grid, s, P); break;
+        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
+        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
+        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
+        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
+        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
+        default: launch_variant<V_TF_CALIB>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
         }
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
@@ -536,6 +546,9 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     };
     if (!hip_ok(hipSetDevice(device_id), "hipSetDevice")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(VR_ERR_HIP);
+    if (const char* e = getenv("VR_EXP_WAVES_PER_BLOCK")) c->waves_per_block = (atoi(e) == 1) ? 1 : 4;
+    if (const char* e = getenv("VR_EXP_ONLY_TILE")) c->only_tile = atoi(e);
+    if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
     if (!hip_ok(hipEventCreate(&c->tm.ev_begin), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_k0), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_k1), "hipEventCreate")) return bail(VR_ERR_HIP);
@@ -655,9 +668,13 @@ static int tf_upload_one(vr_ctx* c, int slot, const float* table, uint32_t R, bo
             c->tf_color[slot] = nullptr;
             c->tf[slot].color = nullptr;
             c->tf[slot].res_c = 0;
-            VR_HIP(c, hipMalloc(&c->tf_color[slot], R * sizeof(float4)));
+            VR_HIP(c, hipMalloc(&c->tf_color[slot], ((size_t)R + 2) * sizeof(float4)));
         }
-        VR_HIP(c, hipMemcpyAsync(c->tf_color[slot], table, R * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        // device layout (DevTF): the first and the last texel once more at either end
+        VR_HIP(c, hipMemcpyAsync(c->tf_color[slot] + 1, table, R * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        VR_HIP(c, hipMemcpyAsync(c->tf_color[slot], table, sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        VR_HIP(c, hipMemcpyAsync(c->tf_color[slot] + R + 1, table + 4 * ((size_t)R - 1), sizeof(float4), hipMemcpyHostToDevice,
+                                 c->stream));
         VR_HIP(c, hipStreamSynchronize(c->stream));
         c->tf[slot].color = c->tf_color[slot];
         c->tf[slot].res_c = (int)R;
@@ -668,9 +685,12 @@ static int tf_upload_one(vr_ctx* c, int slot, const float* table, uint32_t R, bo
             c->tf_opacity[slot] = nullptr;
             c->tf[slot].opacity = nullptr;
             c->tf[slot].res_o = 0;
-            VR_HIP(c, hipMalloc(&c->tf_opacity[slot], R * sizeof(float)));
+            VR_HIP(c, hipMalloc(&c->tf_opacity[slot], ((size_t)R + 2) * sizeof(float)));
         }
-        VR_HIP(c, hipMemcpyAsync(c->tf_opacity[slot], table, R * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        VR_HIP(c, hipMemcpyAsync(c->tf_opacity[slot] + 1, table, R * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        VR_HIP(c, hipMemcpyAsync(c->tf_opacity[slot], table, sizeof(float), hipMemcpyHostToDevice, c->stream));
+        VR_HIP(c, hipMemcpyAsync(c->tf_opacity[slot] + R + 1, table + ((size_t)R - 1), sizeof(float), hipMemcpyHostToDevice,
+                                 c->stream));
         VR_HIP(c, hipStreamSynchronize(c->stream));
         c->tf[slot].opacity = c->tf_opacity[slot];
         c->tf[slot].res_o = (int)R;
@@ -860,10 +880,21 @@ int vr_last_counters(vr_ctx* c, uint64_t out[3])
     return VR_OK;
 }
 
+int vr_last_block_trace(vr_ctx* c, uint64_t* out, int capacity)
+{
+    if (!c || capacity < 0 || (capacity > 0 && !out)) return VR_ERR_INVALID_ARG;
+    VR_HIP(c, hipSetDevice(c->device));
+    if (c->cnt_stream) VR_HIP(c, hipStreamSynchronize(c->cnt_stream));
+    const int n = c->cnt_blocks < capacity ? c->cnt_blocks : capacity;
+    if (n > 0)
+        VR_HIP(c, hipMemcpy(out, c->d_block_counts, (size_t)n * kBlockRecord * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return c->cnt_blocks;
+}
+
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 5) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 6) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

@@ -8,6 +8,7 @@ namespace vr {
 
 constexpr int kTile = 64;        // multi-GPU ownership granule (pixels)
 constexpr int kBlockEdge = 16;   // one 256-thread workgroup = 16x16 pixels = four 8x8 wave packets
+constexpr int kBlockRecord = 6;  // u64 words per block in MarchParams::block_counts
 constexpr int kBlocksPerTile = (kTile / kBlockEdge) * (kTile / kBlockEdge);
 constexpr int kBrickShift = 3;    // empty-space bricks: 8x8x8 base cells
 constexpr int kDistMax = 16;      // cap of the brick distance field (leaps of up to 15 bricks)
@@ -17,9 +18,12 @@ struct DevVolume {
     int nx, ny, nz;
 };
 
+// Both tables are stored with their first and their last texel repeated once at either end: table[k] is at [k+1].
+// The clamp-to-edge texel pair (i0, i1) of a linear fetch is then ALWAYS the adjacent pair [j], [j+1] with
+// j = clamp(floor(x) + 1, 0, R): one index, no second clamp, and the second texel sits at a fixed offset.
 struct DevTF {
-    const float* opacity;  // R32Float[res_o]     (OpacityTf.cpp:25-26)
-    const float4* color;   // RGBA32Float[res_c]  (ColorTf.cpp:23-24)
+    const float* opacity;  // R32Float[res_o + 2]     (OpacityTf.cpp:25-26)
+    const float4* color;   // RGBA32Float[res_c + 2]  (ColorTf.cpp:23-24)
     int res_o, res_c;
 };
 
@@ -39,6 +43,8 @@ struct MarchParams {
     // work decomposition: the launch walks the 64x64 tiles t = rank + n*world, n = 0..n_tiles-1
     int rank, world, tiles_x, tiles_y, n_tiles;
     int packed;              // 0: write frame[y*W+x]; 1: write packed tiles
+    int prio_mode;           // 1: wavefronts with long remaining ray paths raise their issue priority (s_setprio)
+    int only_tile;           // experiment (VR_EXP_ONLY_TILE): >= 0 -> rays of every other tile ordinal do not march
     int n_blocks;            // logical blocks = n_tiles * kBlocksPerTile (grid is padded to a multiple of 8)
     // exact empty-space skipping (BASIC / LIGHT / THREE_FILES): per-brick maximum density of vol[0] over the
     // 9x9x9 voxels an 8x8x8 block of base cells can touch, and the length of the opacity table's zero prefix
@@ -52,7 +58,7 @@ struct MarchParams {
     float bsx, bsy, bsz;     // n/8 per axis of vol[skip_vol] (exact in f32)
     int tf_zero_prefix;      // largest Z with opacity[0..Z] == 0 exactly (-1: none)
     float4* out;
-    unsigned long long* block_counts;  // [gridDim.x][3]: composited samples, covered pixels, samples fetched
+    unsigned long long* block_counts;  // [gridDim.x][kBlockRecord]: composited, covered, fetched, t0, t1, hw id
 };
 
 }  // namespace vr

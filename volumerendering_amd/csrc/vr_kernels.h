@@ -31,9 +31,31 @@ struct f3 {
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
+// 1.0f / sqrtf(x), both operations correctly rounded (the normative normalize = v * (1 / sqrt(dot))).  For x in
+// [2^-60, 2^60) the compiler's IEEE expansions need none of their scaling and special-case steps; what is left is
+// written out here (13 instructions instead of 30).  Everything else -- 0, denormals, huge, inf, NaN, negative --
+// takes the generic operators.
+__device__ __forceinline__ float inv_sqrt_exact(float x)
+{
+    if (__float_as_uint(x) - 0x21800000u < 0x3c000000u) {
+        // v_sqrt_f32 is within 1 ulp: choose among y - 1 ulp, y, y + 1 ulp by the sign of the exact residuals
+        float y = __builtin_amdgcn_sqrtf(x);
+        const float yd = __int_as_float(__float_as_int(y) - 1), yu = __int_as_float(__float_as_int(y) + 1);
+        const float rd = fmaf(-yd, y, x), ru = fmaf(-yu, y, x);
+        y = (rd <= 0.0f) ? yd : y;
+        y = (ru > 0.0f) ? yu : y;
+        // 1 / y: reciprocal estimate, one Newton step, then two residual corrections of the quotient
+        float r = __builtin_amdgcn_rcpf(y);
+        r = fmaf(fmaf(-y, r, 1.0f), r, r);
+        float q = r;
+        q = fmaf(fmaf(-y, q, 1.0f), r, q);
+        return fmaf(fmaf(-y, q, 1.0f), r, q);
+    }
+    return 1.0f / sqrtf(x);
+}
 __device__ __forceinline__ f3 normalize3(f3 a)
 {
-    float inv = 1.0f / length3(a);
+    float inv = inv_sqrt_exact(dot3(a, a));
     return mk3(a.x * inv, a.y * inv, a.z * inv);
 }
 __device__ __forceinline__ float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
@@ -96,6 +118,14 @@ struct Cell {  // the 2x2x2 texel cell of one linear 3-D fetch
     float fx, fy, fz;
 };
 
+// One axis of texel_pair(): i0 = clamp(t, 0, n-1) and whether i1 = clamp(t+1, 0, n-1) is the NEXT texel (it is
+// unless the pair is clamped at either edge: t < 0 or t >= n-1).
+__device__ __forceinline__ void texel_step(float x0, int n, int& i0, bool& next)
+{
+    const int t = min((int)x0, n - 1);  // saturating conversion, NaN -> 0
+    i0 = max(t, 0);
+    next = (unsigned)t < (unsigned)(n - 1);
+}
 __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
 {
     float x = p.x * (float)v.nx - 0.5f;
@@ -106,18 +136,23 @@ __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
     c.fx = x - x0;
     c.fy = y - y0;
     c.fz = z - z0;
-    int i0, i1, j0, j1, k0, k1;
-    texel_pair(x0, v.nx, i0, i1);
-    texel_pair(y0, v.ny, j0, j1);
-    texel_pair(z0, v.nz, k0, k1);
-    unsigned r00 = ((unsigned)k0 * (unsigned)v.ny + (unsigned)j0) * (unsigned)v.nx;
-    unsigned r10 = ((unsigned)k0 * (unsigned)v.ny + (unsigned)j1) * (unsigned)v.nx;
-    unsigned r01 = ((unsigned)k1 * (unsigned)v.ny + (unsigned)j0) * (unsigned)v.nx;
-    unsigned r11 = ((unsigned)k1 * (unsigned)v.ny + (unsigned)j1) * (unsigned)v.nx;
-    c.o000 = r00 + (unsigned)i0; c.o100 = r00 + (unsigned)i1;
-    c.o010 = r10 + (unsigned)i0; c.o110 = r10 + (unsigned)i1;
-    c.o001 = r01 + (unsigned)i0; c.o101 = r01 + (unsigned)i1;
-    c.o011 = r11 + (unsigned)i0; c.o111 = r11 + (unsigned)i1;
+    // the same eight voxel indices as texel_pair() on each axis gives, built from one base index and three
+    // strides that are 0 where the pair is clamped
+    int i0, j0, k0;
+    bool sx, sy, sz;
+    texel_step(x0, v.nx, i0, sx);
+    texel_step(y0, v.ny, j0, sy);
+    texel_step(z0, v.nz, k0, sz);
+    const unsigned row = (unsigned)v.nx, slab = (unsigned)v.nx * (unsigned)v.ny;
+    const unsigned dx = sx ? 1u : 0u, dy = sy ? row : 0u, dz = sz ? slab : 0u;
+    c.o000 = ((unsigned)k0 * (unsigned)v.ny + (unsigned)j0) * row + (unsigned)i0;
+    c.o100 = c.o000 + dx;
+    c.o010 = c.o000 + dy;
+    c.o110 = c.o010 + dx;
+    c.o001 = c.o000 + dz;
+    c.o101 = c.o001 + dx;
+    c.o011 = c.o001 + dy;
+    c.o111 = c.o011 + dx;
     return c;
 }
 
@@ -154,33 +189,90 @@ __device__ __forceinline__ float tri(float v000, float v100, float v010, float v
     return lerpf(c0, c1, fz);
 }
 
+// The eight corners of one linear 3-D fetch as loaded (possibly still in flight) + the interpolation weights.
+// Fetch and interpolation are separate so that the march loop can issue the NEXT step's loads before it waits for
+// this step's transfer-function texels.
+struct Fetch4 {
+    float4 a, b, d, e, f, g, h, i;  // corners 000 100 010 110 001 101 011 111
+};
+struct Fetch1 {
+    float a, b, d, e, f, g, h, i;
+};
+// (The three interpolation weights travel as separate scalars: as adjacent struct members the vectoriser merges
+// their stores and the struct then survives as memory -- the back end parks it in LDS.)
+template <bool OFF32>
+__device__ __forceinline__ void fetch_rgba(const DevVolume& v, f3 p, Fetch4& q, float& fx, float& fy, float& fz)
+{
+    Cell c = make_cell(v, p);
+    q.a = load_vec4<OFF32>(v.data, c.o000); q.b = load_vec4<OFF32>(v.data, c.o100);
+    q.d = load_vec4<OFF32>(v.data, c.o010); q.e = load_vec4<OFF32>(v.data, c.o110);
+    q.f = load_vec4<OFF32>(v.data, c.o001); q.g = load_vec4<OFF32>(v.data, c.o101);
+    q.h = load_vec4<OFF32>(v.data, c.o011); q.i = load_vec4<OFF32>(v.data, c.o111);
+    fx = c.fx;
+    fy = c.fy;
+    fz = c.fz;
+}
+template <bool OFF32>
+__device__ __forceinline__ void fetch_a(const DevVolume& v, f3 p, Fetch1& q, float& fx, float& fy, float& fz)
+{
+    Cell c = make_cell(v, p);
+    q.a = load_a<OFF32>(v.data, c.o000); q.b = load_a<OFF32>(v.data, c.o100);
+    q.d = load_a<OFF32>(v.data, c.o010); q.e = load_a<OFF32>(v.data, c.o110);
+    q.f = load_a<OFF32>(v.data, c.o001); q.g = load_a<OFF32>(v.data, c.o101);
+    q.h = load_a<OFF32>(v.data, c.o011); q.i = load_a<OFF32>(v.data, c.o111);
+    fx = c.fx;
+    fy = c.fy;
+    fz = c.fz;
+}
+// Two channels at a time (packed f32 on the register halves the 16-byte loads deliver: no shuffling).  Per lane
+// and per channel the operations and their order are those of tri(): a + (b - a) * t, separately rounded.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f lerp2(v2f a, v2f b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ v2f tri2(v2f v000, v2f v100, v2f v010, v2f v110, v2f v001, v2f v101, v2f v011, v2f v111,
+                                    float fx, float fy, float fz)
+{
+    v2f c00 = lerp2(v000, v100, fx);
+    v2f c10 = lerp2(v010, v110, fx);
+    v2f c01 = lerp2(v001, v101, fx);
+    v2f c11 = lerp2(v011, v111, fx);
+    v2f c0 = lerp2(c00, c10, fy);
+    v2f c1 = lerp2(c01, c11, fy);
+    return lerp2(c0, c1, fz);
+}
+__device__ __forceinline__ v2f lo2(const float4& v) { return v2f{v.x, v.y}; }
+__device__ __forceinline__ v2f hi2(const float4& v) { return v2f{v.z, v.w}; }
+__device__ __forceinline__ v2f interp_zw(const Fetch4& q, float fx, float fy, float fz)  // (gradient z, density)
+{
+    return tri2(hi2(q.a), hi2(q.b), hi2(q.d), hi2(q.e), hi2(q.f), hi2(q.g), hi2(q.h), hi2(q.i), fx, fy, fz);
+}
+__device__ __forceinline__ v2f interp_xy(const Fetch4& q, float fx, float fy, float fz)  // (gradient x, gradient y)
+{
+    return tri2(lo2(q.a), lo2(q.b), lo2(q.d), lo2(q.e), lo2(q.f), lo2(q.g), lo2(q.h), lo2(q.i), fx, fy, fz);
+}
+__device__ __forceinline__ float interp_a(const Fetch1& q, float fx, float fy, float fz)
+{
+    return tri(q.a, q.b, q.d, q.e, q.f, q.g, q.h, q.i, fx, fy, fz);
+}
+
 // textureSample(vol, samplerLin, p) -> all four channels
 template <bool OFF32>
 __device__ __forceinline__ float4 tex3_rgba(const DevVolume& v, f3 p)
 {
-    Cell c = make_cell(v, p);
-    float4 a = load_vec4<OFF32>(v.data, c.o000), b = load_vec4<OFF32>(v.data, c.o100);
-    float4 d = load_vec4<OFF32>(v.data, c.o010), e = load_vec4<OFF32>(v.data, c.o110);
-    float4 f = load_vec4<OFF32>(v.data, c.o001), g = load_vec4<OFF32>(v.data, c.o101);
-    float4 h = load_vec4<OFF32>(v.data, c.o011), i = load_vec4<OFF32>(v.data, c.o111);
-    float4 r;
-    r.x = tri(a.x, b.x, d.x, e.x, f.x, g.x, h.x, i.x, c.fx, c.fy, c.fz);
-    r.y = tri(a.y, b.y, d.y, e.y, f.y, g.y, h.y, i.y, c.fx, c.fy, c.fz);
-    r.z = tri(a.z, b.z, d.z, e.z, f.z, g.z, h.z, i.z, c.fx, c.fy, c.fz);
-    r.w = tri(a.w, b.w, d.w, e.w, f.w, g.w, h.w, i.w, c.fx, c.fy, c.fz);
-    return r;
+    Fetch4 q;
+    float fx, fy, fz;
+    fetch_rgba<OFF32>(v, p, q, fx, fy, fz);
+    const v2f zw = interp_zw(q, fx, fy, fz), xy = interp_xy(q, fx, fy, fz);
+    return make_float4(xy.x, xy.y, zw.x, zw.y);
 }
 
 // textureSample(vol, samplerLin, p).a  -- only the density plane of the vec4 voxels is touched
 template <bool OFF32>
 __device__ __forceinline__ float tex3_a(const DevVolume& v, f3 p)
 {
-    Cell c = make_cell(v, p);
-    float a = load_a<OFF32>(v.data, c.o000), b = load_a<OFF32>(v.data, c.o100);
-    float d = load_a<OFF32>(v.data, c.o010), e = load_a<OFF32>(v.data, c.o110);
-    float f = load_a<OFF32>(v.data, c.o001), g = load_a<OFF32>(v.data, c.o101);
-    float h = load_a<OFF32>(v.data, c.o011), i = load_a<OFF32>(v.data, c.o111);
-    return tri(a, b, d, e, f, g, h, i, c.fx, c.fy, c.fz);
+    Fetch1 q;
+    float fx, fy, fz;
+    fetch_a<OFF32>(v, p, q, fx, fy, fz);
+    return interp_a(q, fx, fy, fz);
 }
 
 // textureSample(vol, samplerNN, p)  (TFCalibrationApp.wgsl:172)
@@ -198,24 +290,50 @@ struct TfSample {
     float opacity;
     f3 rgb;
 };
-__device__ __forceinline__ TfSample tf_lookup(const DevTF& tf, float d)
+struct TfFetch {  // the four texels of one opacity + colour look-up as loaded, + the weights
+    float o0, o1, fo, fc;
+    float4 c0, c1;
+};
+__device__ __forceinline__ int padded_texel(float x0, int n)
+{
+    // texel_pair(x0, n) is (j - 1, j) clamped to [0, n-1] = entries [j], [j+1] of the padded table (DevTF);
+    // min before the +1 so that it cannot overflow (the conversion saturates, NaN -> 0)
+    return max(min((int)x0, n - 1) + 1, 0);
+}
+__device__ __forceinline__ TfFetch tf_fetch(const DevTF& tf, float d)
 {
     // the opacity and the colour texture are separate 1-D textures, each with its own resolution
     float xo = d * (float)tf.res_o - 0.5f;
     float xo0 = floorf(xo);
-    float fo = xo - xo0;
-    int o0i, o1i, c0i, c1i;
-    texel_pair(xo0, tf.res_o, o0i, o1i);
+    TfFetch q;
+    q.fo = xo - xo0;
     float xc = d * (float)tf.res_c - 0.5f;
     float xc0 = floorf(xc);
-    float fc = xc - xc0;
-    texel_pair(xc0, tf.res_c, c0i, c1i);
-    float o0 = tf.opacity[o0i], o1 = tf.opacity[o1i];
-    float4 c0 = tf.color[c0i], c1 = tf.color[c1i];
+    q.fc = xc - xc0;
+    // tables are far below 4 GiB: SGPR base + 32-bit byte offset
+    const unsigned ob = (unsigned)padded_texel(xo0, tf.res_o) << 2;
+    const unsigned cb = (unsigned)padded_texel(xc0, tf.res_c) << 4;
+    const char* po = reinterpret_cast<const char*>(tf.opacity) + ob;
+    const char* pc = reinterpret_cast<const char*>(tf.color) + cb;
+    q.o0 = reinterpret_cast<const float*>(po)[0];
+    q.o1 = reinterpret_cast<const float*>(po)[1];
+    q.c0 = reinterpret_cast<const float4*>(pc)[0];
+    q.c1 = reinterpret_cast<const float4*>(pc)[1];
+    return q;
+}
+__device__ __forceinline__ TfSample tf_finish(const TfFetch& q)
+{
     TfSample s;
-    s.opacity = lerpf(o0, o1, fo);
-    s.rgb = mk3(lerpf(c0.x, c1.x, fc), lerpf(c0.y, c1.y, fc), lerpf(c0.z, c1.z, fc));
+    s.opacity = lerpf(q.o0, q.o1, q.fo);
+    s.rgb = mk3(lerpf(q.c0.x, q.c1.x, q.fc), lerpf(q.c0.y, q.c1.y, q.fc), lerpf(q.c0.z, q.c1.z, q.fc));
     return s;
+}
+__device__ __forceinline__ TfSample tf_lookup(const DevTF& tf, float d) { return tf_finish(tf_fetch(tf, d)); }
+// Pins the point where the texels are first needed: arithmetic on them cannot be moved above this statement, so
+// loads issued before it (the next step's corners) are in flight while the wave waits for the texels.
+__device__ __forceinline__ void tf_pin(TfFetch& q)
+{
+    asm volatile("" : "+v"(q.o0), "+v"(q.o1), "+v"(q.c0.x), "+v"(q.c0.y), "+v"(q.c0.z), "+v"(q.c1.x), "+v"(q.c1.y), "+v"(q.c1.z));
 }
 
 // ------------------------------------------------------------------------------------------------ ray set-up
@@ -399,20 +517,24 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
     // correctness).  The 16 blocks of one 64x64 tile stay on ONE XCD (their rays traverse neighbouring voxels:
     // shared L2 lines), while consecutive tiles go to different XCDs so that every XCD gets an even share of the
     // heavy (volume-covered) and the empty parts of the screen.
+    // A block is 1 or 4 wavefronts (blockDim.x 64 / 256); a tile is 64 packets of 8x8 pixels either way, packet
+    // pk = 4 * (16x16 sub-block) + quadrant.
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int n = xcd + 8 * (q / kBlocksPerTile);  // ordinal of the owned tile this block works on
-    const int sub = q % kBlocksPerTile;
+    const int wpb = blockDim.x >> 6, bpt = 64 / wpb;  // wavefronts per block, blocks per tile
+    const int n = xcd + 8 * (q / bpt);  // ordinal of the owned tile this block works on
+    const int pk = (q % bpt) * wpb + (threadIdx.x >> 6);
+    const int sub = pk >> 2;
     const bool in_launch = n < P.n_tiles;
     const int t = P.rank + n * P.world;
     const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = pk & 3, lane = threadIdx.x & 63;
     const int lx = ((wave & 1) << 3) + (lane & 7);
     const int ly = ((wave >> 1) << 3) + (lane >> 3);
     const int tpx = ((sub & 3) << 4) + lx, tpy = ((sub >> 2) << 4) + ly;  // pixel inside the tile
     s.px = tx * kTile + tpx;
     s.py = ty * kTile + tpy;
     s.in_launch = in_launch;
-    s.active = in_launch && (s.px < P.W) && (s.py < P.H);
+    s.active = in_launch && (s.px < P.W) && (s.py < P.H) && (P.only_tile < 0 || P.only_tile == n);
     s.out_index = P.packed ? (n * (kTile * kTile) + tpy * kTile + tpx) : (s.py * P.W + s.px);
     return s;
 }
@@ -451,7 +573,8 @@ __device__ __forceinline__ bool brick_inert(const MarchParams& P, float2 rec)
 // triple per wavefront on three shared addresses -- ~37 k device-scope atomics per 1080p frame -- serialised at the
 // memory side and cost 0.3 ms per frame.)  sum_block_counts_kernel adds the blocks up.  Every thread of the block
 // must call this (it contains a barrier).
-__device__ __forceinline__ void store_block_counts(const MarchParams& P, unsigned blends, unsigned covered, unsigned fetched)
+__device__ __forceinline__ void store_block_counts(const MarchParams& P, unsigned blends, unsigned covered, unsigned fetched,
+                                                   unsigned long long t_start)
 {
     __shared__ unsigned long long part[4][2];
     unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
@@ -467,11 +590,20 @@ __device__ __forceinline__ void store_block_counts(const MarchParams& P, unsigne
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long pc = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-        unsigned long long* o = P.block_counts + (size_t)blockIdx.x * 3;
+        unsigned long long pc = 0, fc = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+            pc += part[i][0];
+            fc += part[i][1];
+        }
+        unsigned long long* o = P.block_counts + (size_t)blockIdx.x * kBlockRecord;
         o[0] = pc & ((1ull << 40) - 1);
         o[1] = pc >> 40;
-        o[2] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+        o[2] = fc;
+        // block trace (vr_last_block_trace): 100 MHz clock at entry / exit, HW_ID | XCC_ID << 32
+        o[3] = t_start;
+        o[4] = wall_clock64();
+        o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
     }
 }
 
@@ -536,6 +668,7 @@ __device__ __forceinline__ float leap_axis(float p, float s, float bs, int nb, i
 template <int V, bool OFF32, bool SKIP, int LEAP>
 __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
 {
+    const unsigned long long t_start = wall_clock64();
     PixelSlot slot = map_pixel(P);
     float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     unsigned blends = 0, covered = 0, fetched = 0;
@@ -590,23 +723,56 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                     const float f = fminf(fminf(fx, fy), fminf(fz, 1.0e6f)) * 0.999f - 2.0f;
                     if (in0 && f > 0.0f) n_inside = (int)f;  // NaN / negative -> 0
                 }
-                // Empty-space test, software-pipelined and branch-free: every iteration loads the distance-field byte
-                // of the NEXT position (the same rounded additions the advance performs, so it is the position the next
-                // iteration really has) and consumes it one iteration later.  With 64 rays per wavefront some lane
-                // enters a new brick almost every step; a load-and-wait inside a divergent branch would stall the whole
-                // wavefront each time, an unconditional load whose lanes hit the same one or two lines does not.
-                unsigned D = 0;  // 0: active brick; k >= 1: inert, and so is everything within k-1 bricks
-                if constexpr (SKIP) D = P.brick_dist[brick_of(P, p)];
-                const int lim = min(n_inside, P.steps_count);  // leaps stay inside the provably-in-box prefix
-                // LEAP == 2: steps a ray at distance-field value D can take while it certainly stays within D-1 bricks
-                // of its brick on every axis = (D - 1 - 1/16) / (largest per-step move in brick units), 0.1 % short
+                // ---- the march loop ---------------------------------------------------------------------------------
+                // Empty-space test: one byte per brick (distance field), looked up for the positions AHEAD of the ray
+                // (the same rounded additions the advance performs, so they are the positions later iterations really
+                // have).  Loads complete in order, so WHERE a byte is waited for decides what else is waited for:
+                //   D   byte of p            always arrived
+                //   Dn  byte of p + step     arrived for rays that sampled last iteration (`have`)
+                //   Dq  byte of p + 2 step   (of p + step at the loop head for the other rays): requested one
+                //                            iteration earlier, possibly still in flight, only ever read behind a wait
+                // Rays that did not sample last iteration take their byte in a block of their own at the loop head; a
+                // wavefront whose rays are all inside tissue skips that block, and the eight corner loads it has issued
+                // for the next step (kPipe) stay in flight from the shading of one step to the interpolation of the next.
+                constexpr bool kRun = SKIP && (LEAP >= 2);                              // wave-uniform runs of identity steps
+                constexpr bool kPipe = (V == V_LIGHT || V == V_BASIC) && LEAP != 3 && LEAP != 1;  // corner prefetch
+                unsigned D = 0, Dn = 0, Dq = 0, Dn2 = 0;
+                bool have = false;   // the previous iteration sampled: corners of p requested (F4 / F1), Dn arrived
+                bool stale = false;  // ... and the one before did, this one did not: Dq was not requested
+                Fetch4 F4;
+                Fetch1 F1;
+                float wfx = 0.0f, wfy = 0.0f, wfz = 0.0f;
+                if constexpr (SKIP) {
+                    D = P.brick_dist[brick_of(P, p)];
+                    Dq = P.brick_dist[brick_of(P, mk3(p.x + step.x, p.y + step.y, p.z + step.z))];
+                    asm volatile("" : "+v"(D));  // wait for D here; Dq stays in flight
+                }
+                const int lim = min(n_inside, P.steps_count);  // runs stay inside the provably-in-box prefix
+                const int prio_q1 = P.steps_count >> 2, prio_q2 = P.steps_count >> 1, prio_q3 = prio_q1 + prio_q2;
+                // kRun: steps a ray at distance-field value D can take while it certainly stays within D-1 bricks of
+                // its brick on every axis = (D - 1 - 1/16) / (largest per-step move in brick units), 0.1 % short
                 float leap_c = 0.0f;
-                if constexpr (LEAP == 2) {
+                if constexpr (kRun) {
                     const float vmax = fmaxf(fmaxf(fabsf(step.x) * P.bsx, fabsf(step.y) * P.bsy), fabsf(step.z) * P.bsz);
                     leap_c = 0.999f / vmax;  // vmax 0 -> inf (capped below), NaN -> n_inside is 0 and nothing leaps
                 }
                 for (int i = 0; i < P.steps_count;) {
-                    if constexpr (LEAP == 2) {
+                    f3 pn = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                    const f3 pq = mk3(pn.x + step.x, pn.y + step.y, pn.z + step.z);
+                    if constexpr (SKIP) {
+                        if (!have) {
+                            if constexpr (kPipe) {
+                                if (stale) Dq = P.brick_dist[brick_of(P, pn)];  // first iteration after leaving tissue
+                                stale = false;
+                            }
+                            // requested an iteration ago.  (The copy is spelled out so that it happens HERE and the new
+                            // load can go into Dq's own register: a compiler-placed copy behind the load would wait.)
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(Dn) : "v"(Dq));
+                            __builtin_amdgcn_sched_barrier(0);
+                            Dq = P.brick_dist[brick_of(P, pq)];
+                        }
+                    }
+                    if constexpr (kRun) {
                         // Wave-uniform run of identity steps: when EVERY ray of the packet that is still marching sits
                         // at least 4 safe steps inside inert bricks, all of them take the same number of plain rounded
                         // additions back to back (nothing else per step), then look their brick up again.  The rays
@@ -630,24 +796,82 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                             i += mw;
                             blends += (unsigned)mw;
                             D = P.brick_dist[brick_of(P, p)];
+                            Dq = P.brick_dist[brick_of(P, mk3(p.x + step.x, p.y + step.y, p.z + step.z))];
+                            asm volatile("" : "+v"(D));  // (and everything older); Dq stays in flight
+                            have = false;
+                            stale = false;
                             continue;
                         }
                     }
                     bool inb = true;
                     if (i >= n_inside)
                         inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
-                    f3 pn = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
-                    unsigned Dn = 0;
-                    if constexpr (SKIP) Dn = P.brick_dist[brick_of(P, pn)];
                     int adv = 1;  // steps this iteration advances by
                     if (inb) {
                         if (!SKIP || D == 0) {
-                            sample_and_blend<V, OFF32>(P, p, w, dst);
+                            if (P.prio_mode == 1) {
+                                // longest-remaining-path-first: the frame is done when its longest ray is, so wavefronts
+                                // whose rays still have far to go get the issue slots first (4 levels, by quarters of
+                                // stepsCount; speed only)
+                                const int r = lim - i;
+                                if (__ballot(r > prio_q3) != 0) __builtin_amdgcn_s_setprio(3);
+                                else if (__ballot(r > prio_q2) != 0) __builtin_amdgcn_s_setprio(2);
+                                else if (__ballot(r > prio_q1) != 0) __builtin_amdgcn_s_setprio(1);
+                                else __builtin_amdgcn_s_setprio(0);
+                            }
+                            if constexpr (kPipe) {
+                                // Software pipeline over the steps of a ray: the corners of THIS step were requested one
+                                // iteration ago (or are requested now, on entering tissue).  The next step's corners are
+                                // requested after this step's table texels, so waiting for the texels leaves those eight
+                                // loads in flight; the look-ahead byte is taken before them for the same reason.
+                                unsigned R = 0;
+                                if constexpr (SKIP) R = P.brick_dist[brick_of(P, pq)];
+                                TfFetch tq;
+                                f3 grad = mk3(0.0f, 0.0f, 0.0f);
+                                if constexpr (V == V_LIGHT) {
+                                    if (!have) fetch_rgba<OFF32>(P.vol[0], p, F4, wfx, wfy, wfz);
+                                    const v2f zw = interp_zw(F4, wfx, wfy, wfz);
+                                    tq = tf_fetch(P.tf[0], zw.y);
+                                    const v2f xy = interp_xy(F4, wfx, wfy, wfz);
+                                    grad = mk3(xy.x, xy.y, zw.x);
+                                } else {
+                                    if (!have) fetch_a<OFF32>(P.vol[0], p, F1, wfx, wfy, wfz);
+                                    tq = tf_fetch(P.tf[0], interp_a(F1, wfx, wfy, wfz));
+                                }
+                                if constexpr (SKIP) {
+                                    asm volatile("" : "+v"(R));
+                                    Dn2 = R;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);  // the old corners are dead here: same registers
+                                if constexpr (V == V_LIGHT)
+                                    fetch_rgba<OFF32>(P.vol[0], pn, F4, wfx, wfy, wfz);
+                                else
+                                    fetch_a<OFF32>(P.vol[0], pn, F1, wfx, wfy, wfz);
+                                __builtin_amdgcn_sched_barrier(0);
+                                tf_pin(tq);
+                                have = true;
+                                const TfSample t = tf_finish(tq);
+                                if constexpr (V == V_LIGHT) {
+                                    const f3 N = normalize3(grad);
+                                    const f3 sh = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
+                                                        mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
+                                                        mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
+                                    blend(mk3(t.rgb.x * sh.x, t.rgb.y * sh.y, t.rgb.z * sh.z), t.opacity, dst);
+                                } else {
+                                    blend(t.rgb, t.opacity, dst);
+                                }
+                            } else {
+                                sample_and_blend<V, OFF32>(P, p, w, dst);
+                            }
                             ++fetched;
                             ++blends;
                             if (!can_blend<V>(dst.w)) break;  // cut-off reached: no later iteration can blend
                         } else {
                             // identity blend(s): the reference executes them, nothing changes and nothing is fetched
+                            if constexpr (kPipe) {
+                                stale = have;  // leaving tissue: back to the loop-head scheme
+                                have = false;
+                            }
                             if constexpr (LEAP == 1) {
                                 if (D >= 2 && i + 3 < lim) {
                                     const DevVolume& v = P.vol[P.skip_vol];
@@ -677,6 +901,8 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                                             pn = q;
                                             if constexpr (V != V_BASIC && V != V_TF_CALIB) w = wq;
                                             Dn = P.brick_dist[brick_of(P, pn)];
+                                            Dq = P.brick_dist[brick_of(P, mk3(pn.x + step.x, pn.y + step.y, pn.z + step.z))];
+                                            asm volatile("" : "+v"(Dn));
                                         }
                                     }
                                 }
@@ -684,6 +910,10 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                             blends += (unsigned)adv;
                         }
                     } else {
+                        if constexpr (kPipe) {
+                            stale = have;
+                            have = false;
+                        }
                         // p moves monotonically per component: once past the far bound it never returns
                         bool gone = (step.x >= 0.0f && p.x > bx1) || (step.x <= 0.0f && p.x < bx0) ||
                                     (step.y >= 0.0f && p.y > by1) || (step.y <= 0.0f && p.y < by0) ||
@@ -692,6 +922,9 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                     }
                     p = pn;
                     D = Dn;
+                    if constexpr (kPipe) {
+                        if (have) Dn = Dn2;
+                    }
                     if (adv == 1) {
                         if constexpr (V != V_BASIC && V != V_TF_CALIB) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
                     }
@@ -704,7 +937,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
     // packed-tile launches write every slot of an owned tile (pixels outside the viewport = 0)
     if (slot.active || (P.packed && slot.in_launch)) P.out[slot.out_index] = dst;
 
-    store_block_counts(P, blends, covered, fetched);
+    store_block_counts(P, blends, covered, fetched, t_start);
 }
 
 // One wavefront per brick: maximum of .a over the voxels [8b, min(8b+8, n-1)]^3 (NaN if any voxel is NaN).
@@ -777,9 +1010,9 @@ __global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned lo
     __shared__ unsigned long long part[4][3];
     unsigned long long a = 0, b = 0, f = 0;
     for (int i = threadIdx.x; i < n_blocks; i += 256) {
-        a += in[(size_t)i * 3];
-        b += in[(size_t)i * 3 + 1];
-        f += in[(size_t)i * 3 + 2];
+        a += in[(size_t)i * kBlockRecord];
+        b += in[(size_t)i * kBlockRecord + 1];
+        f += in[(size_t)i * kBlockRecord + 2];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

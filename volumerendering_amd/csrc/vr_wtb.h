@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void march_wtb_light_kernel(const MarchParams 
     float4* const tile = tiles + (threadIdx.x >> 6) * kWtbCap;
 
     // work mapping: identical to march_kernel (16x16-pixel blocks, 8x8 packet per wavefront)
+    const unsigned long long t_start = wall_clock64();
     const PixelSlot slot = map_pixel(P);
     const int lane = threadIdx.x & 63;
     const int px = slot.px, py = slot.py;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void march_wtb_light_kernel(const MarchParams 
 
     if (active || (P.packed && in_launch)) P.out[out_index] = dst;
 
-    store_block_counts(P, blends, covered, fetched);
+    store_block_counts(P, blends, covered, fetched, t_start);
 }
 
 }  // namespace vr
