@@ -223,12 +223,16 @@ int vr_last_counters(vr_ctx* ctx, uint64_t out[3]);
  * in blockIdx order.  Writes min(capacity, n) records and returns n (the number of workgroups launched).      */
 int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
 
-/* Kernel flavour for A/B measurements: 0 = default (best: exact empty-space skipping plus
- * wave-uniform runs of plain additions through inert bricks), 1 = no empty-space skipping, 2 = LDS wave tiles
- * without skipping, 3 = LDS wave tiles with skipping (lit shader only; others fall back to 0 / 1), 4 = skipping
- * plus closed-form leaping (f32 accumulation as integer arithmetic on the bit patterns), 5 = skipping alone,
- * one step per iteration.  All
- * flavours are bit-identical in output and in the composited-sample count.                       */
+/* Kernel flavour for A/B measurements.  All flavours are bit-identical in output and in the sample counts.
+ *   0  default: exact empty-space skipping + wave-uniform runs through inert bricks; lanes per ray chosen from
+ *      the size of the launch (one lane per ray when the machine is full of rays, two or four when the frame would
+ *      otherwise wait for its longest rays: small frames, one GPU's share of the tiles)
+ *   1  one lane per ray, no empty-space skipping (every composited sample is fetched)
+ *   2 / 3  LDS wave tiles without / with skipping (lit shader only; others fall back to 1 / 6)
+ *   4  skipping + closed-form leaping (f32 accumulation as integer arithmetic on the bit patterns)
+ *   5  skipping alone, one step per iteration
+ *   6  one lane per ray (forced), 7  four lanes per ray (forced), 8  two lanes per ray (forced)
+ *   9  one lane per ray with the next step's corner loads software-pipelined behind the shading            */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 
 #ifdef __cplusplus

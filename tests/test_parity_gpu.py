@@ -335,10 +335,12 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
                 assert ctx.counters()[2] < 0.5 * ns
 
 
-@pytest.mark.parametrize("flavour", [4, 5])
+@pytest.mark.parametrize("flavour", [4, 5, 6, 7, 8, 9])
 def test_exact_leaping_flavour(ctx, flavour):
-    """Flavour 5 lets a whole ray packet run through inert bricks with plain additions only.  Flavour 4 jumps over m steps at once: bits(x after m additions) = bits(x1) + (m-1)*(bits(x2)-bits(x1)) while
-    sign and exponent hold.  Must reproduce the step-by-step accumulation bit for bit (frames AND sample counts)."""
+    """Every way of getting through empty space and every lanes-per-ray layout must reproduce the step-by-step
+    accumulation bit for bit (frames AND sample counts): 5 single steps, 6 wave-uniform runs of plain additions,
+    4 closed-form jumps (bits(x after m additions) = bits(x1) + (m-1)*(bits(x2)-bits(x1)) while sign and exponent
+    hold), 7 / 8 four / two lanes per ray with the ordered blend, 9 software-pipelined corner loads."""
     n = 96
     raw = np.zeros((n, n, n), dtype=np.uint16)
     raw[40:56, 30:70, 44:60] = 3000
@@ -367,3 +369,42 @@ def test_exact_leaping_flavour(ctx, flavour):
         check(ctx, capi.VOLUME_MASK, hr.make_uniforms(W, H, steps_count=c40, step_size=s40), vols, tfs, W, H)
     finally:
         ctx.set_kernel_flavour(0)
+
+
+@pytest.mark.parametrize("flavour", [6, 7, 8, 9])
+@pytest.mark.parametrize("variant", range(6))
+def test_every_variant_every_layout(ctx, variant, flavour):
+    """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
+    forced here for every shader, with clips / variable step / jitter and a ragged viewport."""
+    W, H = 70, 45
+    vols, tfs = vt.scene(variant, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    try:
+        ctx.set_kernel_flavour(flavour)
+        for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
+                   dict(steps_count=7), dict(distance=0.7, yaw=1.0)):
+            args = dict(steps_count=count, step_size=step)
+            args.update(kw)
+            check(ctx, variant, hr.make_uniforms(W, H, **args), vols, tfs, W, H)
+    finally:
+        ctx.set_kernel_flavour(0)
+
+
+def test_default_layout_follows_launch_size(ctx):
+    """1080p-sized launches take the one-lane kernel, small ones the depth-parallel ones; same frame either way."""
+    W, H = 1920, 1080
+    vols, tfs = vt.scene(capi.LIGHT, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step, distance=2.5)
+    ctx.resize(W, H)
+    try:
+        frames = []
+        for fl in (0, 6, 7, 8):
+            ctx.set_kernel_flavour(fl)
+            frag, _, n = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+            frames.append((vt.bits(frag), n))
+        for b, n in frames[1:]:
+            assert n == frames[0][1] and np.array_equal(b, frames[0][0])
+    finally:
+        ctx.set_kernel_flavour(0)
+        ctx.resize(96, 80)

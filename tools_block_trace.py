@@ -33,6 +33,7 @@ def main():
     tr = ctx.block_trace().astype(np.int64)
     t0, t1 = tr[:, 3], tr[:, 4]
     xcc = (tr[:, 5] >> 32) & 0xF
+    crit = tr[:, 5] >> 40
     hw = tr[:, 5] & 0xFFFFFFFF
     cu = (hw >> 8) & 0xF
     se = (hw >> 13) & 0x7
@@ -53,7 +54,8 @@ def main():
     print("longest workgroups: duration us / start us / fetched / composited / XCD / tile ordinal")
     for i in order:
         tile = (i & 7) + 8 * ((i >> 3) // 16)
-        print(f"   {dur[i]:7.1f} {(t0[i] - base) / 100.0:7.1f} {tr[i, 2]:8d} {tr[i, 0]:8d}   {xcc[i]}  {tile}")
+        print(f"   {dur[i]:7.1f} {(t0[i] - base) / 100.0:7.1f} {tr[i, 2]:8d} {tr[i, 0]:8d}   {xcc[i]}  {tile}  chain {crit[i]}")
+    print(f"longest sample chain {crit.max()}  p99 {np.percentile(crit[heavy], 99):.0f}  median of busy workgroups {np.median(crit[heavy]):.0f}")
     # residency over time (20 bins)
     edges = np.linspace(0, span, 21)
     res = []

@@ -31,7 +31,7 @@ def _sources(d: str, exts: tuple[str, ...]) -> list[str]:
 
 def build_hip(force: bool = False) -> str:
     target = os.path.join(HERE, "libvr_hip.so")
-    deps = [os.path.join(CSRC, f) for f in ("vr_api.hip", "vr_kernels.h", "vr_wtb.h", "vr_device.h")]
+    deps = [os.path.join(CSRC, f) for f in ("vr_api.hip", "vr_kernels.h", "vr_wtb.h", "vr_dp.h", "vr_device.h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "vr.h"))
     if force or _newer(target, deps):
         subprocess.run([HIPCC, *HIP_FLAGS, "-o", target, os.path.join(CSRC, "vr_api.hip")], check=True)

@@ -4,6 +4,7 @@
 #include "../../include/vr.h"
 #include "vr_kernels.h"
 #include "vr_wtb.h"
+#include "vr_dp.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -70,7 +71,10 @@ struct vr_ctx {
     int flavour = 0;
     int waves_per_block = 4;  // 1 or 4 (experiment knob VR_EXP_WAVES_PER_BLOCK)
     int only_tile = -1;       // experiment knob VR_EXP_ONLY_TILE
-    int prio_mode = 0;        // experiment knob VR_EXP_PRIO
+    int prio_mode = 1;        // wave priority by remaining ray path (VR_EXP_PRIO=0 switches it off)
+    int n_cus = 256;          // compute units of the device
+    int default_flavour = 0;  // what flavour 0 resolves to (experiment knob VR_EXP_FLAVOUR)
+    int xcd_mode = 1;         // deal a tile's workgroups over the XCDs (VR_EXP_XCD=0: one XCD per tile)
     std::string err;
 };
 
@@ -163,6 +167,86 @@ void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, 
 #undef VR_LAUNCH
 }
 
+// Inverse of a column-major 4x4 in double precision (cofactors); false if singular / not finite.
+bool invert4(const float* m, double* o)
+{
+    double a[16], inv[16];
+    for (int i = 0; i < 16; ++i) a[i] = m[i];
+    inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+    inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+    inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+    inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+    inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+    inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+    inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+    inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+    inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+    inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+    inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+    inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+    inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+    inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+    inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+    inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+    const double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+    if (!(det - det == 0.0) || det == 0.0) return false;
+    for (int i = 0; i < 16; ++i) {
+        o[i] = inv[i] / det;
+        if (!(o[i] - o[i] == 0.0)) return false;
+    }
+    return true;
+}
+
+// Pixel rectangle outside which no ray can hit the box [-.5,.5]^2 x [-.25,.25]: the rays are defined by proj_inv and
+// view_inv (setup_ray), so the box corners are projected with the inverses of exactly those.  With every corner in
+// front of the eye the box projects inside the hull of its corners; 3 pixels of margin dwarf the rounding.  Anything
+// doubtful (singular matrices, a corner at or behind the eye plane, non-finite numbers) -> the whole frame.
+void hit_rectangle(const vr_uniforms& u, int W, int H, int rect[4])
+{
+    rect[0] = 0;
+    rect[1] = 0;
+    rect[2] = W - 1;
+    rect[3] = H - 1;
+    double proj[16], view[16];
+    if (!invert4(u.proj_inv, proj) || !invert4(u.view_inv, view)) return;
+    double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+    for (int k = 0; k < 8; ++k) {
+        const double wp[4] = {(k & 1) ? 0.5 : -0.5, (k & 2) ? 0.5 : -0.5, (k & 4) ? 0.25 : -0.25, 1.0};
+        double e[4], cl[4];
+        for (int r = 0; r < 4; ++r) e[r] = view[r] * wp[0] + view[4 + r] * wp[1] + view[8 + r] * wp[2] + view[12 + r] * wp[3];
+        for (int r = 0; r < 4; ++r) cl[r] = proj[r] * e[0] + proj[4 + r] * e[1] + proj[8 + r] * e[2] + proj[12 + r] * e[3];
+        if (!(cl[3] > 1e-9)) return;
+        const double px = (cl[0] / cl[3] + 1.0) * 0.5 * W, py = (1.0 - cl[1] / cl[3]) * 0.5 * H;
+        if (!(px - px == 0.0) || !(py - py == 0.0)) return;
+        x0 = px < x0 ? px : x0;
+        x1 = px > x1 ? px : x1;
+        y0 = py < y0 ? py : y0;
+        y1 = py > y1 ? py : y1;
+    }
+    auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    rect[0] = (int)clampd(x0 - 3.0, 0.0, (double)W);
+    rect[1] = (int)clampd(y0 - 3.0, 0.0, (double)H);
+    rect[2] = (int)clampd(x1 + 3.0, -1.0, (double)(W - 1));
+    rect[3] = (int)clampd(y1 + 3.0, -1.0, (double)(H - 1));
+}
+
+template <int V, int K>
+void launch_dp(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
+{
+    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
+#define VR_LAUNCH_DP(O, S) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K>), grid, dim3(256), 0, s, P)
+    if constexpr (kCanSkip) {
+        if (P.brick_dist) {
+            if (off32) VR_LAUNCH_DP(true, true);
+            else VR_LAUNCH_DP(false, true);
+            return;
+        }
+    }
+    if (off32) VR_LAUNCH_DP(true, false);
+    else VR_LAUNCH_DP(false, false);
+#undef VR_LAUNCH_DP
+}
+
 bool all_finite(const float* v, int n)
 {
     for (int i = 0; i < n; ++i)
@@ -196,6 +280,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     std::memcpy(P.view_inv, c->u.view_inv, sizeof P.view_inv);
     P.W = (int)c->W;
     P.H = (int)c->H;
+    hit_rectangle(c->u, P.W, P.H, P.rect);
     P.fragment_mode = c->u.fragment_mode;
     P.steps_count = c->u.steps_count;
     P.step_size = c->u.step_size;
@@ -220,13 +305,24 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     P.n_blocks = P.n_tiles * kBlocksPerTile;
     P.only_tile = c->only_tile;
     P.prio_mode = c->prio_mode;
+    P.xcd_mode = c->xcd_mode;
     // exact empty-space skipping: only for the shaders whose opacity is the CT table value alone, only when a
     // zero-opacity sample is provably the identity (finite colour table and light), and unless flavour 1 asks
     // for the plain kernel
     const bool skip_variant = variant == VR_VARIANT_BASIC || variant == VR_VARIANT_LIGHT ||
                               variant == VR_VARIANT_THREE_FILES || variant == VR_VARIANT_VOLUME_MASK;
     const int sv = (variant == VR_VARIANT_VOLUME_MASK) ? 2 : 0;  // the volume whose density drives tf[0]'s opacity
-    bool can_skip = skip_variant && c->flavour != 1 && c->flavour != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
+    int fl = c->flavour == 0 ? c->default_flavour : c->flavour;
+    if (fl == 0) {
+        // Default: pick the lanes per ray from the size of the launch.  With many rays per hardware lane the machine
+        // is throughput-bound and one lane per ray does the least work; with few (a small frame, or one GPU's share
+        // of the tiles) the frame waits for its longest rays, whose chains of dependent steps the depth-parallel
+        // kernel cuts to a half or a quarter (vr_dp.h).  Thresholds measured on C3 at 1 / 2 / 4 / 8 ranks.
+        const long long px = (long long)tile_count(c, rank, world) * kTile * kTile;
+        const double rays_per_lane = (double)px / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
+        fl = rays_per_lane >= 4.5 ? 6 : (rays_per_lane >= 2.0 ? 8 : 7);
+    }
+    bool can_skip = skip_variant && fl != 1 && fl != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
     // the kernels index bricks with 24-bit multiplies and 32-bit byte offsets
     can_skip = can_skip && ((c->vol[sv].nx + 7) >> kBrickShift) * (long long)((c->vol[sv].ny + 7) >> kBrickShift) < (1 << 23);
@@ -306,15 +402,18 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
     if (P.n_blocks > 0) {
         // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
-        const bool wtb = (c->flavour == 2 || c->flavour == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
+        const bool wtb = (fl == 2 || fl == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
+        const int leap_mode = fl == 4 ? 1 : (fl == 5 ? 0 : (fl == 9 ? 2 : 3));
+        const int dp = fl == 7 ? 4 : (fl == 8 ? 2 : 0);  // lanes per ray (vr_dp.h): 64 / 32 workgroups per tile
         const int wpb = wtb ? 4 : c->waves_per_block;
-        dim3 block((unsigned)(64 * wpb));
-        dim3 grid((unsigned)((P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // whole tiles per XCD, see map_pixel
+        dim3 block((unsigned)(dp ? 256 : 64 * wpb));
+        dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 64 : 32) : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel
         if (grid.x > c->block_counts_cap) {
             if (c->d_block_counts) (void)hipFree(c->d_block_counts);
             c->d_block_counts = nullptr;
             c->block_counts_cap = 0;
             VR_HIP(c, hipMalloc(&c->d_block_counts, (size_t)grid.x * kBlockRecord * sizeof(unsigned long long)));
+            VR_HIP(c, hipMemsetAsync(c->d_block_counts, 0, (size_t)grid.x * kBlockRecord * sizeof(unsigned long long), s));
             c->block_counts_cap = grid.x;
         }
         P.block_counts = c->d_block_counts;
@@ -329,14 +428,32 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, false>), grid, dim3(256), 0, s, P);
                 else hipLaunchKernelGGL((march_wtb_light_kernel<false, false>), grid, dim3(256), 0, s, P);
             }
+        } else if (dp == 4) {
+            switch (variant) {
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4>(off32, grid, s, P); break;
+            case VR_VARIANT_LIGHT: launch_dp<V_LIGHT, 4>(off32, grid, s, P); break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4>(off32, grid, s, P); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4>(off32, grid, s, P); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4>(off32, grid, s, P); break;
+            default: launch_dp<V_TF_CALIB, 4>(off32, grid, s, P); break;
+            }
+        } else if (dp == 2) {
+            switch (variant) {
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2>(off32, grid, s, P); break;
+            case VR_VARIANT_LIGHT: launch_dp<V_LIGHT, 2>(off32, grid, s, P); break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2>(off32, grid, s, P); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2>(off32, grid, s, P); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2>(off32, grid, s, P); break;
+            default: launch_dp<V_TF_CALIB, 2>(off32, grid, s, P); break;
+            }
         } else
         switch (variant) {
-        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
-        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
-        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
-        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
-        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
-        default: launch_variant<V_TF_CALIB>(off32, c->flavour == 4 ? 1 : (c->flavour == 5 ? 0 : (c->flavour == 6 ? 3 : 2)), grid, block, s, P); break;
+        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, P); break;
+        default: launch_variant<V_TF_CALIB>(off32, leap_mode, grid, block, s, P); break;
         }
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
@@ -546,9 +663,16 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     };
     if (!hip_ok(hipSetDevice(device_id), "hipSetDevice")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(VR_ERR_HIP);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->n_cus = cus;
+    }
+    // experiment knobs (A/B measurements; none changes any result)
     if (const char* e = getenv("VR_EXP_WAVES_PER_BLOCK")) c->waves_per_block = (atoi(e) == 1) ? 1 : 4;
     if (const char* e = getenv("VR_EXP_ONLY_TILE")) c->only_tile = atoi(e);
     if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
+    if (const char* e = getenv("VR_EXP_FLAVOUR")) c->default_flavour = atoi(e);
+    if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (!hip_ok(hipEventCreate(&c->tm.ev_begin), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_k0), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_k1), "hipEventCreate")) return bail(VR_ERR_HIP);
@@ -894,7 +1018,7 @@ int vr_last_block_trace(vr_ctx* c, uint64_t* out, int capacity)
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 6) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 9) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

@@ -44,7 +44,9 @@ struct MarchParams {
     int rank, world, tiles_x, tiles_y, n_tiles;
     int packed;              // 0: write frame[y*W+x]; 1: write packed tiles
     int prio_mode;           // 1: wavefronts with long remaining ray paths raise their issue priority (s_setprio)
+    int xcd_mode;            // 0: the blocks of a tile share an XCD, 1: they are dealt over the XCDs
     int only_tile;           // experiment (VR_EXP_ONLY_TILE): >= 0 -> rays of every other tile ordinal do not march
+    int rect[4];             // x0, y0, x1, y1 (inclusive): no ray outside this pixel rectangle can hit the box
     int n_blocks;            // logical blocks = n_tiles * kBlocksPerTile (grid is padded to a multiple of 8)
     // exact empty-space skipping (BASIC / LIGHT / THREE_FILES): per-brick maximum density of vol[0] over the
     // 9x9x9 voxels an 8x8x8 block of base cells can touch, and the length of the opacity table's zero prefix

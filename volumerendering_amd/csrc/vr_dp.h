@@ -1,0 +1,247 @@
+// Depth-parallel march kernel: FOUR lanes per ray.
+//
+// The expensive part of a step -- eight corner loads, interpolation, table look-ups, shading -- does not depend on
+// the accumulated colour; only FrontToBackBlend and the opacity cut-off are sequential.  So the four lanes of a quad
+// take four CONSECUTIVE steps of one ray, sample them at the same time, and the quad then blends the four results
+// in step order (quad-broadcast DPP, every lane keeps an identical copy of dst).  Per sample nothing changes -- the
+// same positions (each lane runs the ray's chain of rounded additions itself, four additions per round), the same
+// arithmetic, the same blend order, the same sample counts -- but a ray's chain of dependent work is a quarter as long and
+// a wavefront is 16 rays (a 4x4 pixel packet) instead of 64.  That is what the frame time hangs on: with one lane per
+// ray the frame waits for the wavefronts with the longest rays (per-workgroup trace, tools_block_trace.py: longest
+// workgroup 0.9 ms of a 0.93 ms frame while the average busy workgroup takes 0.42 ms), and a GPU that owns an eighth of
+// the tiles is hardly faster than one that owns all of them.  Loop overhead (look-ahead, run test, box test) is also
+// paid once per round of four steps instead of once per step.
+//
+// Reference loop: BasicVolumeApp.wgsl:167-185 and the five other shaders (see vr_kernels.h, march_kernel).
+#pragma once
+#include "vr_kernels.h"
+
+namespace vr {
+
+// The value depth slot J of the lane's own ray holds (K lanes per ray, K = 2 or 4, rays aligned to quads).
+template <int K, int J>
+__device__ __forceinline__ int slot_bcast(int v)
+{
+    // quad_perm:[J,J,J,J] for K = 4, [J,J,2+J,2+J] for K = 2
+    constexpr int ctrl = (K == 4) ? (J | (J << 2) | (J << 4) | (J << 6)) : (J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6));
+    return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true);
+}
+template <int K, int J>
+__device__ __forceinline__ float slot_bcast(float v)
+{
+    return __int_as_float(slot_bcast<K, J>(__float_as_int(v)));
+}
+
+// K = 4: 8x8-pixel workgroups (64 per 64x64 tile), a wavefront = a 4x4 pixel packet; K = 2: 16x8-pixel workgroups
+// (32 per tile), a wavefront = an 8x4 packet.  ray = lane / K, depth slot = lane % K.  Consecutive workgroups of a
+// tile run on consecutive XCDs, so every XCD gets an even sample of the screen.
+template <int K>
+__device__ __forceinline__ PixelSlot map_pixel_dp(const MarchParams& P)
+{
+    PixelSlot s;
+    constexpr int kBpt = (K == 4) ? 64 : 32;  // workgroups per tile
+    const int n = blockIdx.x / kBpt;          // ordinal of the owned tile this block works on
+    const int sub = blockIdx.x % kBpt;
+    const bool in_launch = n < P.n_tiles;
+    const int t = P.rank + n * P.world;
+    const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+    const int wave = threadIdx.x >> 6, ray = (threadIdx.x & 63) / K;
+    int tpx, tpy;  // pixel inside the tile
+    if constexpr (K == 4) {
+        tpx = ((sub & 7) << 3) + ((wave & 1) << 2) + (ray & 3);
+        tpy = ((sub >> 3) << 3) + ((wave >> 1) << 2) + (ray >> 2);
+    } else {
+        tpx = ((sub & 3) << 4) + ((wave & 1) << 3) + (ray & 7);
+        tpy = ((sub >> 2) << 3) + ((wave >> 1) << 2) + (ray >> 3);
+    }
+    s.px = tx * kTile + tpx;
+    s.py = ty * kTile + tpy;
+    s.in_launch = in_launch;
+    s.active = in_launch && (s.px < P.W) && (s.py < P.H) && (P.only_tile < 0 || P.only_tile == n);
+    s.out_index = P.packed ? (n * (kTile * kTile) + tpy * kTile + tpx) : (s.py * P.W + s.px);
+    return s;
+}
+
+// One step of the ordered blend: the lanes of a ray take the result of depth slot J.  dst is kept as two register
+// pairs (xy, zw) so that the blend is two packed multiplies and two packed adds.
+template <int V, int K, int J>
+__device__ __forceinline__ void dp_blend_slot(int flags, v2f s_rg, v2f s_ba, v2f& dxy, v2f& dzw, bool& alive, unsigned& blends,
+                                              unsigned& fetched)
+{
+    const int f = slot_bcast<K, J>(flags);
+    const v2f rg = v2f{slot_bcast<K, J>(s_rg.x), slot_bcast<K, J>(s_rg.y)};
+    const v2f ba = v2f{slot_bcast<K, J>(s_ba.x), slot_bcast<K, J>(s_ba.y)};
+    const bool counted = alive && (f & 1);   // in the sample box: the reference executes the blend
+    const bool real = counted && (f & 2);    // ... and it is not a provable identity
+    blends += counted ? 1u : 0u;
+    fetched += real ? 1u : 0u;
+    const float om = 1.0f - dzw.y;           // FrontToBackBlend, src already (rgb * a, a)
+    const v2f nxy = rg * om + dxy, nzw = ba * om + dzw;
+    dxy = real ? nxy : dxy;
+    dzw = real ? nzw : dzw;
+    const bool cut = real && !can_blend<V>(dzw.y);        // cut-off reached: no later step can blend
+    const bool left = alive && !(f & 1) && (f & 4);      // past the far side of the sample box
+    alive = alive && !cut && !left;
+}
+
+template <int V, bool OFF32, bool SKIP, int K>
+__global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
+{
+    const unsigned long long t_start = wall_clock64();
+    const PixelSlot slot = map_pixel_dp<K>(P);
+    const int j = threadIdx.x & (K - 1);  // depth slot
+    float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    unsigned blends = 0, covered = 0, fetched = 0;
+    bool alive = false;
+    f3 p = mk3(0.0f, 0.0f, 0.0f), w = p, step = p, wstep = p;
+    int n_inside = 0;
+    const float bx0 = P.bmin[0], by0 = P.bmin[1], bz0 = P.bmin[2];
+    const float bx1 = P.bmax[0], by1 = P.bmax[1], bz1 = P.bmax[2];
+
+    if (slot.active && slot.px >= P.rect[0] && slot.px <= P.rect[2] && slot.py >= P.rect[1] && slot.py <= P.rect[3]) {
+        Ray ray = setup_ray(P, slot.px, slot.py);
+        if (ray.hit) {
+            covered = 1;
+            f3 diff = mk3(ray.end.x - ray.start.x, ray.end.y - ray.start.y, ray.end.z - ray.start.z);
+            f3 dir = normalize3(diff);
+            float ray_len = length3(diff);
+            if (P.fragment_mode == 1) {
+                dst = make_float4(fabsf(dir.x), fabsf(dir.y), fabsf(dir.z), 1.0f);
+            } else if (P.fragment_mode == 2) {
+                dst = make_float4(ray.start.x, ray.start.y, ray.start.z, 1.0f);
+            } else if (P.fragment_mode == 3) {
+                dst = make_float4(ray.end.x, ray.end.y, ray.end.z, 1.0f);
+            } else if (P.fragment_mode == 4) {
+                dst = make_float4(0.5f * (ray.world0.x / 1.0f) + 0.5f, -0.5f * (ray.world0.y / 1.0f) + 0.5f, 0.0f, 1.0f);
+            } else {
+                // the per-pixel prologue of march_kernel, unchanged
+                float step_size = P.step_size;
+                if constexpr (V == V_LIGHT) {  // CalculateWorldStep before the override
+                    wstep = mk3(dir.x * (step_size * 1.0f), dir.y * (step_size * 1.0f), dir.z * (step_size * 0.5f));
+                    wstep.z = wstep.z * (-1.0f);
+                }
+                if (P.toggle_varstep == 1) step_size = ray_len / (float)P.steps_count;
+                p = ray.start;
+                if (P.toggle_jitter == 1) {
+                    float jt = jitter((float)slot.px + 0.5f, (float)slot.py + 0.5f);
+                    p = mk3(p.x + (dir.x * step_size) * jt, p.y + (dir.y * step_size) * jt, p.z + (dir.z * step_size) * jt);
+                }
+                step = mk3(dir.x * step_size, dir.y * step_size, dir.z * step_size);
+                if constexpr (V == V_MULTI_CTRT) {  // CalculateWorldStep after the override
+                    wstep = mk3(dir.x * (step_size * 1.0f), dir.y * (step_size * 1.0f), dir.z * (step_size * 0.7f));
+                    wstep.z = wstep.z * (-1.0f);
+                }
+                if constexpr (V == V_VOLUME_MASK || V == V_THREE_FILES) wstep = step;
+                w = ray.world0;
+                {
+                    const float fx = step.x > 0.0f ? (bx1 - p.x) / step.x : (step.x < 0.0f ? (bx0 - p.x) / step.x : 3.0e38f);
+                    const float fy = step.y > 0.0f ? (by1 - p.y) / step.y : (step.y < 0.0f ? (by0 - p.y) / step.y : 3.0e38f);
+                    const float fz = step.z > 0.0f ? (bz1 - p.z) / step.z : (step.z < 0.0f ? (bz0 - p.z) / step.z : 3.0e38f);
+                    const bool in0 = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
+                    const float f = fminf(fminf(fx, fy), fminf(fz, 1.0e6f)) * 0.999f - 2.0f;
+                    if (in0 && f > 0.0f) n_inside = (int)f;  // NaN / negative -> 0
+                }
+                alive = true;
+            }
+        }
+    }
+
+    // ---- the march: every lane of the wavefront runs the loop (rays that are done are predicated off), so the
+    // quad broadcasts and the wavefront votes below always see all their lanes
+    constexpr bool kW = (V != V_BASIC && V != V_TF_CALIB);  // the shader uses the world position
+    // depth slot j starts j steps down the ray: the same rounded additions the one-lane loop performs
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) {
+        if (k < j) {
+            p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+            if constexpr (kW) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+        }
+    }
+    unsigned D = 0;  // distance-field byte of p: 0 = sample, k >= 1 = identity, and so is everything within k-1 bricks
+    if constexpr (SKIP) D = P.brick_dist[brick_of(P, p)];
+    const int lim = min(n_inside, P.steps_count);  // runs stay inside the provably-in-box prefix
+    float leap_c = 0.0f;
+    if constexpr (SKIP) {
+        const float vmax = fmaxf(fmaxf(fabsf(step.x) * P.bsx, fabsf(step.y) * P.bsy), fabsf(step.z) * P.bsz);
+        leap_c = 0.999f / vmax;  // see march_kernel
+    }
+
+    v2f dxy = v2f{0.0f, 0.0f}, dzw = dxy;  // dst of the marching rays (fragment modes 1-4 keep theirs in `dst`)
+    int base = 0;  // step index of depth slot 0 (wave-uniform)
+    while (base < P.steps_count && __ballot(alive) != 0) {
+        const int my = base + j;
+        // next round: K more rounded additions; its distance-field byte is requested now, used at the bottom
+        f3 pn = p, wn = w;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            pn = mk3(pn.x + step.x, pn.y + step.y, pn.z + step.z);
+            if constexpr (kW) wn = mk3(wn.x + wstep.x, wn.y + wstep.y, wn.z + wstep.z);
+        }
+        unsigned Dn = 0;
+        if constexpr (SKIP) Dn = P.brick_dist[brick_of(P, pn)];
+
+        if constexpr (SKIP) {
+            // wave-uniform run of identity steps (march_kernel): every slot of every ray that is still marching
+            // has at least 4 safe steps -> all of them advance by the same count; the ray passes steps
+            // [base, base + mw), all inside the inert neighbourhood of slot 0 and inside the box
+            int m = 1 << 30;
+            if (alive) m = (D >= 2) ? min((int)fminf(((float)D - 1.0625f) * leap_c, 64.0f), lim - my - 1) : 0;
+            if (__ballot(m < 4) == 0) {
+                int mw = 4;
+                if (__ballot(m < 8) == 0) {
+                    mw = 8;
+                    if (__ballot(m < 16) == 0) {
+                        mw = 16;
+                        if (__ballot(m < 32) == 0) mw = __ballot(m < 64) == 0 ? 64 : 32;
+                    }
+                }
+                for (int k = 0; k < mw; ++k) {
+                    p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                    if constexpr (kW) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                }
+                base += mw;
+                blends += alive ? (unsigned)mw : 0u;
+                D = P.brick_dist[brick_of(P, p)];
+                continue;
+            }
+        }
+
+        // this slot's step
+        const bool valid = alive && my < P.steps_count;
+        bool inb = valid, gone = false;
+        if (my >= n_inside) {
+            inb = valid && p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
+            // p moves monotonically per component: once past the far bound it never returns
+            gone = valid && !inb &&
+                   ((step.x >= 0.0f && p.x > bx1) || (step.x <= 0.0f && p.x < bx0) || (step.y >= 0.0f && p.y > by1) ||
+                    (step.y <= 0.0f && p.y < by0) || (step.z >= 0.0f && p.z > bz1) || (step.z <= 0.0f && p.z < bz0));
+        }
+        const bool real = inb && (!SKIP || D == 0);
+        v2f s_rg = v2f{0.0f, 0.0f}, s_ba = s_rg;
+        if (real) {
+            const Src s = sample_src<V, OFF32>(P, p, w);
+            s_rg = v2f{s.rgb.x * s.a, s.rgb.y * s.a};
+            s_ba = v2f{s.rgb.z * s.a, s.a};
+        }
+        const int flags = (inb ? 1 : 0) | (real ? 2 : 0) | (gone ? 4 : 0);
+        // the K results, in step order
+        dp_blend_slot<V, K, 0>(flags, s_rg, s_ba, dxy, dzw, alive, blends, fetched);
+        dp_blend_slot<V, K, 1>(flags, s_rg, s_ba, dxy, dzw, alive, blends, fetched);
+        if constexpr (K == 4) {
+            dp_blend_slot<V, K, 2>(flags, s_rg, s_ba, dxy, dzw, alive, blends, fetched);
+            dp_blend_slot<V, K, 3>(flags, s_rg, s_ba, dxy, dzw, alive, blends, fetched);
+        }
+
+        p = pn;
+        w = wn;
+        D = Dn;
+        base += K;
+    }
+
+    if (P.fragment_mode < 1 || P.fragment_mode > 4) dst = make_float4(dxy.x, dxy.y, dzw.x, dzw.y);
+    // slot 0 of every ray holds (like the others) the ray's result and counts
+    if (j == 0 && (slot.active || (P.packed && slot.in_launch))) P.out[slot.out_index] = dst;
+    store_block_counts(P, j == 0 ? blends : 0u, j == 0 ? covered : 0u, j == 0 ? fetched : 0u, t_start);
+}
+
+}  // namespace vr

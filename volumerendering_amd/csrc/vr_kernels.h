@@ -432,14 +432,21 @@ __device__ __forceinline__ bool can_blend(float a)  // the shader's opacity cut-
         return a < 1.0f;
 }
 
-// One loop iteration's body for a position that passed IsInSampleCoords and the cut-off.
+// What one sample contributes before the blend: colour and opacity of the position p (w = world position), for a
+// position that passed IsInSampleCoords and the cut-off.
+struct Src {
+    f3 rgb;
+    float a;
+};
 template <int V, bool OFF32>
-__device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst)
+__device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w)
 {
+    Src o;
     if constexpr (V == V_BASIC) {
         float density = tex3_a<OFF32>(P.vol[0], p);
         TfSample t = tf_lookup(P.tf[0], density);
-        blend(t.rgb, t.opacity, dst);
+        o.rgb = t.rgb;
+        o.a = t.opacity;
     } else if constexpr (V == V_LIGHT) {
         float4 v = tex3_rgba<OFF32>(P.vol[0], p);
         TfSample t = tf_lookup(P.tf[0], v.w);
@@ -447,7 +454,8 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         f3 s = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
                      mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
                      mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
-        blend(mk3(t.rgb.x * s.x, t.rgb.y * s.y, t.rgb.z * s.z), t.opacity, dst);
+        o.rgb = mk3(t.rgb.x * s.x, t.rgb.y * s.y, t.rgb.z * s.z);
+        o.a = t.opacity;
     } else if constexpr (V == V_VOLUME_MASK) {
         float4 mask = tex3_rgba<OFF32>(P.vol[0], p);
         float rt = tex3_a<OFF32>(P.vol[1], p);
@@ -456,22 +464,21 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         TfSample tct = tf_lookup(P.tf[0], ct.w);
         f3 N = normalize3(mk3(ct.x, ct.y, ct.z));
         f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(0.96f, 0.76f, 0.67f), mk3(1.0f, 1.0f, 1.0f), 1.5f, 0.5f);
-        f3 col = mk3(tct.rgb.x * s.x, tct.rgb.y * s.y, tct.rgb.z * s.z);
-        float opacity = tct.opacity;
+        o.rgb = mk3(tct.rgb.x * s.x, tct.rgb.y * s.y, tct.rgb.z * s.z);
+        o.a = tct.opacity;
         if (mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) {
-            opacity = trt.opacity;
-            col = trt.rgb;
+            o.a = trt.opacity;
+            o.rgb = trt.rgb;
         }
-        blend(col, opacity, dst);
     } else if constexpr (V == V_THREE_FILES) {
         float ct = tex3_a<OFF32>(P.vol[0], p);
         float rt = tex3_a<OFF32>(P.vol[1], p);
         TfSample tct = tf_lookup(P.tf[0], ct);
         TfSample trt = tf_lookup(P.tf[1], rt);
         float om = 1.0f - trt.opacity;
-        f3 col = mk3(tct.rgb.x * om + trt.rgb.x * trt.opacity, tct.rgb.y * om + trt.rgb.y * trt.opacity,
-                     tct.rgb.z * om + trt.rgb.z * trt.opacity);
-        blend(col, tct.opacity, dst);
+        o.rgb = mk3(tct.rgb.x * om + trt.rgb.x * trt.opacity, tct.rgb.y * om + trt.rgb.y * trt.opacity,
+                    tct.rgb.z * om + trt.rgb.z * trt.opacity);
+        o.a = tct.opacity;
     } else if constexpr (V == V_MULTI_CTRT) {
         float4 ct = tex3_rgba<OFF32>(P.vol[0], p);
         float rt = tex3_a<OFF32>(P.vol[1], p);
@@ -484,9 +491,8 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         f3 N = normalize3(g);
         f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
                      mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 3.5f, 0.5f);
-        col = mk3(col.x * s.x, col.y * s.y, col.z * s.z);
-        float opacity = tct.opacity * length3(g);
-        blend(col, opacity, dst);
+        o.rgb = mk3(col.x * s.x, col.y * s.y, col.z * s.z);
+        o.a = tct.opacity * length3(g);
     } else {  // V_TF_CALIB
         float density = tex3_a<OFF32>(P.vol[0], p);
         float4 mask = tex3_nearest<OFF32>(P.vol[1], p);
@@ -495,8 +501,16 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
             t.rgb = mk3(1.0f, 1.0f, 0.0f);
             t.opacity = 0.1f;
         }
-        blend(t.rgb, t.opacity, dst);
+        o.rgb = t.rgb;
+        o.a = t.opacity;
     }
+    return o;
+}
+template <int V, bool OFF32>
+__device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst)
+{
+    const Src s = sample_src<V, OFF32>(P, p, w);
+    blend(s.rgb, s.a, dst);
 }
 
 // ------------------------------------------------------------------------------------------------ work mapping
@@ -521,8 +535,12 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
     // pk = 4 * (16x16 sub-block) + quadrant.
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int wpb = blockDim.x >> 6, bpt = 64 / wpb;  // wavefronts per block, blocks per tile
-    const int n = xcd + 8 * (q / bpt);  // ordinal of the owned tile this block works on
-    const int pk = (q % bpt) * wpb + (threadIdx.x >> 6);
+    int n = xcd + 8 * (q / bpt);  // ordinal of the owned tile this block works on
+    int pk = (q % bpt) * wpb + (threadIdx.x >> 6);
+    if (P.xcd_mode == 1) {  // consecutive blocks of a tile on consecutive XCDs: every XCD gets an even sample of the screen
+        n = blockIdx.x / bpt;
+        pk = (blockIdx.x % bpt) * wpb + (threadIdx.x >> 6);
+    }
     const int sub = pk >> 2;
     const bool in_launch = n < P.n_tiles;
     const int t = P.rank + n * P.world;
@@ -576,24 +594,28 @@ __device__ __forceinline__ bool brick_inert(const MarchParams& P, float2 rec)
 __device__ __forceinline__ void store_block_counts(const MarchParams& P, unsigned blends, unsigned covered, unsigned fetched,
                                                    unsigned long long t_start)
 {
-    __shared__ unsigned long long part[4][2];
+    __shared__ unsigned long long part[4][3];
     unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
     unsigned long long fetched_cnt = fetched;
+    unsigned crit = fetched;  // most samples any one ray of the wavefront fetched ~ its chain of dependent iterations
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         packed_cnt += __shfl_down(packed_cnt, off, 64);
         fetched_cnt += __shfl_down(fetched_cnt, off, 64);
+        crit = max(crit, (unsigned)__shfl_down((int)crit, off, 64));
     }
     if ((threadIdx.x & 63) == 0) {
         part[threadIdx.x >> 6][0] = packed_cnt;
         part[threadIdx.x >> 6][1] = fetched_cnt;
+        part[threadIdx.x >> 6][2] = crit;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long pc = 0, fc = 0;
+        unsigned long long pc = 0, fc = 0, cr = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
             pc += part[i][0];
             fc += part[i][1];
+            cr = part[i][2] > cr ? part[i][2] : cr;
         }
         unsigned long long* o = P.block_counts + (size_t)blockIdx.x * kBlockRecord;
         o[0] = pc & ((1ull << 40) - 1);
@@ -602,8 +624,9 @@ __device__ __forceinline__ void store_block_counts(const MarchParams& P, unsigne
         // block trace (vr_last_block_trace): 100 MHz clock at entry / exit, HW_ID | XCC_ID << 32
         o[3] = t_start;
         o[4] = wall_clock64();
+        // HW_ID | XCC_ID << 32 | longest per-ray sample chain of the workgroup << 40
         o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
-               ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
+               ((unsigned long long)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xffu) << 32) | (cr << 40);
     }
 }
 
@@ -673,7 +696,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
     float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     unsigned blends = 0, covered = 0, fetched = 0;
 
-    if (slot.active) {
+    if (slot.active && slot.px >= P.rect[0] && slot.px <= P.rect[2] && slot.py >= P.rect[1] && slot.py <= P.rect[3]) {
         Ray ray = setup_ray(P, slot.px, slot.py);
         if (ray.hit) {
             covered = 1;
