@@ -35,6 +35,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level
 # per-composited-sample algorithmic bytes: the f32 footprint of one trilinear cell
 BYTES_PER_SAMPLE = {"BASIC": 32, "LIGHT": 128, "VOLUME_MASK": 288, "THREE_FILES": 64, "MULTI_CTRT": 160, "TF_CALIB": 48}
 
+# which kernel a resolved flavour runs (include/vr.h, vr_set_kernel_flavour)
+KERNEL_OF_FLAVOUR = {1: "march_kernel (no skipping)", 2: "march_wtb_light_kernel", 3: "march_wtb_light_kernel",
+                     6: "march_kernel (one lane per ray)", 7: "march_dp_kernel (4 lanes per ray)",
+                     8: "march_dp_kernel (2 lanes per ray)", 9: "march_kernel (one lane per ray, pipelined)",
+                     10: "march_dp_kernel (4 lanes per ray, pipelined)", 11: "march_dp_kernel (2 lanes per ray, pipelined)"}
+
 WORKLOADS = {
     # name: (volume N, W, H, variant)
     "C1": (64, 256, 256, "BASIC"),
@@ -256,6 +262,7 @@ def main():
         except Exception:
             traffic = None
 
+    ran = ctx.last_kernel_flavour()
     out = {
         "metric": "Gsamples/s", "value": round(value, 4), "unit": "Gsamples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -267,12 +274,12 @@ def main():
             "partition": "single GPU" if world == 1 else
                          f"64x64 image tiles interleaved over {world} GPUs + RCCL gather (pipelined one frame deep)",
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
-            "covered_pixels": covered, "kernel_flavour": args.flavour,
+            "covered_pixels": covered, "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-            "kernel": "march_kernel", "kernel_ms": round(kernel_ms, 4), "bytes_per_sample": bs,
+            "kernel": KERNEL_OF_FLAVOUR.get(ran, "march_kernel"), "kernel_ms": round(kernel_ms, 4), "bytes_per_sample": bs,
             "algorithmic_bytes_per_launch": alg_bytes,
         },
     }

@@ -232,8 +232,13 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *   4  skipping + closed-form leaping (f32 accumulation as integer arithmetic on the bit patterns)
  *   5  skipping alone, one step per iteration
  *   6  one lane per ray (forced), 7  four lanes per ray (forced), 8  two lanes per ray (forced)
- *   9  one lane per ray with the next step's corner loads software-pipelined behind the shading            */
+ *   9  one lane per ray with the next step's corner loads software-pipelined behind the shading
+ *   10 / 11  four / two lanes per ray with the next round's corner loads software-pipelined (lit shader; what
+ *      the default uses for small launches)                                                                  */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
+
+/* The flavour the last render actually ran (what 0 resolved to for that launch), or a negative vr_status. */
+int vr_last_kernel_flavour(vr_ctx* ctx);
 
 #ifdef __cplusplus
 }

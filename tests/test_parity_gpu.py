@@ -335,7 +335,7 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
                 assert ctx.counters()[2] < 0.5 * ns
 
 
-@pytest.mark.parametrize("flavour", [4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("flavour", [4, 5, 6, 7, 8, 9, 10, 11])
 def test_exact_leaping_flavour(ctx, flavour):
     """Every way of getting through empty space and every lanes-per-ray layout must reproduce the step-by-step
     accumulation bit for bit (frames AND sample counts): 5 single steps, 6 wave-uniform runs of plain additions,
@@ -371,7 +371,7 @@ def test_exact_leaping_flavour(ctx, flavour):
         ctx.set_kernel_flavour(0)
 
 
-@pytest.mark.parametrize("flavour", [6, 7, 8, 9])
+@pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("variant", range(6))
 def test_every_variant_every_layout(ctx, variant, flavour):
     """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
@@ -399,7 +399,7 @@ def test_default_layout_follows_launch_size(ctx):
     ctx.resize(W, H)
     try:
         frames = []
-        for fl in (0, 6, 7, 8):
+        for fl in (0, 6, 7, 8, 10, 11):
             ctx.set_kernel_flavour(fl)
             frag, _, n = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
             frames.append((vt.bits(frag), n))

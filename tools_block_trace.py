@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--tf", default="default")
     ap.add_argument("--flavour", type=int, default=0)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--world", type=int, default=1, help="trace rank's share of the tiles (tile t -> rank t mod world)")
     a = ap.parse_args()
     import bench
     from volumerendering_amd import capi, host, synth
@@ -29,7 +31,10 @@ def main():
     ctx = app.context()
     ctx.set_kernel_flavour(a.flavour)
     for _ in range(3):
-        app.OnRender()
+        if a.world > 1:
+            ctx.render_tiles(variant, a.rank, a.world)
+        else:
+            app.OnRender()
     tr = ctx.block_trace().astype(np.int64)
     t0, t1 = tr[:, 3], tr[:, 4]
     xcc = (tr[:, 5] >> 32) & 0xF

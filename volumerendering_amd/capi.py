@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "vr_volume_upload_device", "vr_volume_upload_raw16", "vr_volume_upload_raw32", "vr_volume_normalize",
     "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
-    "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace",
+    "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
 ]
 
 
@@ -103,6 +103,7 @@ def load() -> C.CDLL:
     lib.vr_last_counters.argtypes = [vp, C.POINTER(C.c_uint64 * 3)]
     lib.vr_last_block_trace.argtypes = [vp, C.c_void_p, C.c_int]
     lib.vr_set_kernel_flavour.argtypes = [vp, i32]
+    lib.vr_last_kernel_flavour.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -266,6 +267,9 @@ class Context:
 
     def frame_device_ptr(self) -> int:
         return int(self.lib.vr_frame_device_ptr(self.h) or 0)
+
+    def last_kernel_flavour(self) -> int:
+        return self._chk(self.lib.vr_last_kernel_flavour(self.h))
 
     def set_kernel_flavour(self, flavour: int):
         self._chk(self.lib.vr_set_kernel_flavour(self.h, flavour))

@@ -74,6 +74,7 @@ struct vr_ctx {
     int prio_mode = 1;        // wave priority by remaining ray path (VR_EXP_PRIO=0 switches it off)
     int n_cus = 256;          // compute units of the device
     int default_flavour = 0;  // what flavour 0 resolves to (experiment knob VR_EXP_FLAVOUR)
+    int last_flavour = 0;     // the flavour the last launch resolved to
     int xcd_mode = 1;         // deal a tile's workgroups over the XCDs (VR_EXP_XCD=0: one XCD per tile)
     std::string err;
 };
@@ -230,11 +231,11 @@ void hit_rectangle(const vr_uniforms& u, int W, int H, int rect[4])
     rect[3] = (int)clampd(y1 + 3.0, -1.0, (double)(H - 1));
 }
 
-template <int V, int K>
+template <int V, int K, bool PIPE>
 void launch_dp(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
-#define VR_LAUNCH_DP(O, S) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K>), grid, dim3(256), 0, s, P)
+#define VR_LAUNCH_DP(O, S) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K, PIPE>), grid, dim3(256), 0, s, P)
     if constexpr (kCanSkip) {
         if (P.brick_dist) {
             if (off32) VR_LAUNCH_DP(true, true);
@@ -320,8 +321,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // kernel cuts to a half or a quarter (vr_dp.h).  Thresholds measured on C3 at 1 / 2 / 4 / 8 ranks.
         const long long px = (long long)tile_count(c, rank, world) * kTile * kTile;
         const double rays_per_lane = (double)px / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
-        fl = rays_per_lane >= 4.5 ? 6 : (rays_per_lane >= 2.0 ? 8 : 7);
+        fl = rays_per_lane >= 4.5 ? 6 : (rays_per_lane >= 2.0 ? 11 : 10);
     }
+    c->last_flavour = fl;
     bool can_skip = skip_variant && fl != 1 && fl != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
     // the kernels index bricks with 24-bit multiplies and 32-bit byte offsets
@@ -404,7 +406,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
         const bool wtb = (fl == 2 || fl == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
         const int leap_mode = fl == 4 ? 1 : (fl == 5 ? 0 : (fl == 9 ? 2 : 3));
-        const int dp = fl == 7 ? 4 : (fl == 8 ? 2 : 0);  // lanes per ray (vr_dp.h): 64 / 32 workgroups per tile
+        const int dp = (fl == 7 || fl == 10) ? 4 : ((fl == 8 || fl == 11) ? 2 : 0);
+        const bool dp_pipe = fl == 10 || fl == 11;  // ... with the next round's corner loads software-pipelined  // lanes per ray (vr_dp.h): 64 / 32 workgroups per tile
         const int wpb = wtb ? 4 : c->waves_per_block;
         dim3 block((unsigned)(dp ? 256 : 64 * wpb));
         dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 64 : 32) : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel
@@ -430,21 +433,27 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             }
         } else if (dp == 4) {
             switch (variant) {
-            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4>(off32, grid, s, P); break;
-            case VR_VARIANT_LIGHT: launch_dp<V_LIGHT, 4>(off32, grid, s, P); break;
-            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4>(off32, grid, s, P); break;
-            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4>(off32, grid, s, P); break;
-            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4>(off32, grid, s, P); break;
-            default: launch_dp<V_TF_CALIB, 4>(off32, grid, s, P); break;
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4, false>(off32, grid, s, P); break;
+            case VR_VARIANT_LIGHT:
+                if (dp_pipe) launch_dp<V_LIGHT, 4, true>(off32, grid, s, P);
+                else launch_dp<V_LIGHT, 4, false>(off32, grid, s, P);
+                break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4, false>(off32, grid, s, P); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4, false>(off32, grid, s, P); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4, false>(off32, grid, s, P); break;
+            default: launch_dp<V_TF_CALIB, 4, false>(off32, grid, s, P); break;
             }
         } else if (dp == 2) {
             switch (variant) {
-            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2>(off32, grid, s, P); break;
-            case VR_VARIANT_LIGHT: launch_dp<V_LIGHT, 2>(off32, grid, s, P); break;
-            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2>(off32, grid, s, P); break;
-            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2>(off32, grid, s, P); break;
-            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2>(off32, grid, s, P); break;
-            default: launch_dp<V_TF_CALIB, 2>(off32, grid, s, P); break;
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2, false>(off32, grid, s, P); break;
+            case VR_VARIANT_LIGHT:
+                if (dp_pipe) launch_dp<V_LIGHT, 2, true>(off32, grid, s, P);
+                else launch_dp<V_LIGHT, 2, false>(off32, grid, s, P);
+                break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2, false>(off32, grid, s, P); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2, false>(off32, grid, s, P); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2, false>(off32, grid, s, P); break;
+            default: launch_dp<V_TF_CALIB, 2, false>(off32, grid, s, P); break;
             }
         } else
         switch (variant) {
@@ -1015,10 +1024,16 @@ int vr_last_block_trace(vr_ctx* c, uint64_t* out, int capacity)
     return c->cnt_blocks;
 }
 
+int vr_last_kernel_flavour(vr_ctx* c)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    return c->last_flavour;
+}
+
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 9) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 11) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

@@ -84,7 +84,7 @@ __device__ __forceinline__ void dp_blend_slot(int flags, v2f s_rg, v2f s_ba, v2f
     alive = alive && !cut && !left;
 }
 
-template <int V, bool OFF32, bool SKIP, int K>
+template <int V, bool OFF32, bool SKIP, int K, bool PIPE>
 __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
 {
     const unsigned long long t_start = wall_clock64();
@@ -158,7 +158,10 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
         }
     }
     unsigned D = 0;  // distance-field byte of p: 0 = sample, k >= 1 = identity, and so is everything within k-1 bricks
-    if constexpr (SKIP) D = P.brick_dist[brick_of(P, p)];
+    if constexpr (SKIP) {
+        D = P.brick_dist[brick_of(P, p)];
+        if constexpr (PIPE) asm volatile("" : "+v"(D));
+    }
     const int lim = min(n_inside, P.steps_count);  // runs stay inside the provably-in-box prefix
     float leap_c = 0.0f;
     if constexpr (SKIP) {
@@ -167,6 +170,9 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
     }
 
     v2f dxy = v2f{0.0f, 0.0f}, dzw = dxy;  // dst of the marching rays (fragment modes 1-4 keep theirs in `dst`)
+    bool have = false;  // this slot sampled last round: the corners of its current position are requested (F4)
+    Fetch4 F4;
+    float wfx = 0.0f, wfy = 0.0f, wfz = 0.0f;
     int base = 0;  // step index of depth slot 0 (wave-uniform)
     while (base < P.steps_count && __ballot(alive) != 0) {
         const int my = base + j;
@@ -202,6 +208,8 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
                 base += mw;
                 blends += alive ? (unsigned)mw : 0u;
                 D = P.brick_dist[brick_of(P, p)];
+                if constexpr (PIPE) asm volatile("" : "+v"(D));  // no path reaches the loop head with a load pending
+                have = false;
                 continue;
             }
         }
@@ -218,11 +226,39 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
         }
         const bool real = inb && (!SKIP || D == 0);
         v2f s_rg = v2f{0.0f, 0.0f}, s_ba = s_rg;
+        // (PIPE: the look-ahead byte is taken here, on the straight-line path: a wait placed behind the divergent
+        // sampling block could not tell the paths apart and would wait for the corner loads issued inside it)
+        if constexpr (PIPE && SKIP) asm volatile("" : "+v"(Dn));
         if (real) {
-            const Src s = sample_src<V, OFF32>(P, p, w);
-            s_rg = v2f{s.rgb.x * s.a, s.rgb.y * s.a};
-            s_ba = v2f{s.rgb.z * s.a, s.a};
+            if constexpr (PIPE && V == V_LIGHT) {
+                // The corners of this position were requested at the end of the previous round (or are requested now,
+                // on entering tissue); the next round's are requested after this round's table texels, so the wait for
+                // the texels leaves them in flight behind the shading, the ordered blend and the next loop head: a
+                // launch small enough to need this kernel waits on memory latency, not on issue slots.
+                if (!have) fetch_rgba<OFF32>(P.vol[0], p, F4, wfx, wfy, wfz);
+                const v2f zw = interp_zw(F4, wfx, wfy, wfz);
+                TfFetch tq = tf_fetch(P.tf[0], zw.y);
+                const v2f xy = interp_xy(F4, wfx, wfy, wfz);
+                const f3 grad = mk3(xy.x, xy.y, zw.x);
+                __builtin_amdgcn_sched_barrier(0);  // the old corners are dead here: same registers
+                fetch_rgba<OFF32>(P.vol[0], pn, F4, wfx, wfy, wfz);
+                __builtin_amdgcn_sched_barrier(0);
+                tf_pin(tq);
+                const TfSample t = tf_finish(tq);
+                const f3 N = normalize3(grad);
+                const f3 sh = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
+                                    mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
+                                    mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
+                const f3 col = mk3(t.rgb.x * sh.x, t.rgb.y * sh.y, t.rgb.z * sh.z);
+                s_rg = v2f{col.x * t.opacity, col.y * t.opacity};
+                s_ba = v2f{col.z * t.opacity, t.opacity};
+            } else {
+                const Src s = sample_src<V, OFF32>(P, p, w);
+                s_rg = v2f{s.rgb.x * s.a, s.rgb.y * s.a};
+                s_ba = v2f{s.rgb.z * s.a, s.a};
+            }
         }
+        have = real;
         const int flags = (inb ? 1 : 0) | (real ? 2 : 0) | (gone ? 4 : 0);
         // the K results, in step order
         dp_blend_slot<V, K, 0>(flags, s_rg, s_ba, dxy, dzw, alive, blends, fetched);
