@@ -67,3 +67,39 @@ def write_slice(path, pixels, *, modality="CT", rows, cols, frames=None, bits=16
     ds += element(0x7FE00010, "OW", pixels.tobytes(), explicit)
     with open(path, "wb") as f:
         f.write(b"\0" * 128 + b"DICM" + meta + ds)
+
+
+def sequence(tag, items, explicit=True, undefined=True):
+    """A sequence whose own length and item lengths are either all undefined (delimited) or all explicit."""
+    if undefined:
+        return sequence_undefined(tag, items, explicit)
+    body = b"".join(struct.pack("<HHI", 0xFFFE, 0xE000, len(it)) + it for it in items)
+    return element(tag, "SQ", body, explicit)
+
+
+def write_rtstruct(path, contours, *, rois=None, colors=None, frame_uid="1.2.3.4", label="LABEL", name="NAME",
+                   modality="RTSTRUCT", explicit=True, undefined=True, fmt=repr):
+    """contours[c] = list of polygons, a polygon = flat list x y z x y z ...  Layout as in PS3.3 C.8.8.5 / C.8.8.6:
+    Referenced Frame of Reference Sequence, Structure Set ROI Sequence (one item per ROI), ROI Contour Sequence (one item
+    per ROI: display colour, Contour Sequence with one item per polygon)."""
+    ts = "1.2.840.10008.1.2.1" if explicit else "1.2.840.10008.1.2"
+    meta = element(0x00020010, "UI", ts, True)
+    meta = element(0x00020000, "UL", struct.pack("<I", len(meta)), True) + meta
+    rois = rois or [(i + 1, f"ROI{i + 1}", "MANUAL") for i in range(len(contours))]
+    colors = colors or [(255, 10 * i, 0) for i in range(len(contours))]
+    ds = element(0x00080060, "CS", modality, explicit)
+    ds += element(0x30060002, "SH", label, explicit)
+    ds += element(0x30060004, "LO", name, explicit)
+    ds += sequence(0x30060010, [element(0x00200052, "UI", frame_uid, explicit)], explicit, undefined)
+    ds += sequence(0x30060020, [element(0x30060022, "IS", str(n), explicit) + element(0x30060024, "UI", frame_uid, explicit) +
+                                element(0x30060026, "LO", nm, explicit) + element(0x30060036, "CS", alg, explicit)
+                                for n, nm, alg in rois], explicit, undefined)
+    items = []
+    for c, polys in enumerate(contours):
+        cs = [element(0x30060042, "CS", "CLOSED_PLANAR", explicit) + element(0x30060046, "IS", str(len(p) // 3), explicit) +
+              element(0x30060050, "DS", "\\".join(fmt(float(v)) for v in p), explicit) for p in polys]
+        items.append(element(0x3006002A, "IS", "\\".join(str(v) for v in colors[c]), explicit) +
+                     sequence(0x30060040, cs, explicit, undefined) + element(0x30060084, "IS", str(rois[c][0]), explicit))
+    ds += sequence(0x30060039, items, explicit, undefined)
+    with open(path, "wb") as f:
+        f.write(b"\0" * 128 + b"DICM" + meta + ds)

@@ -112,3 +112,64 @@ def test_scene_prepared_on_device_equals_host_prepared(variant):
             frag, _, ns = app.ReadFrame()
             frames.append((frag, ns))
     assert np.array_equal(vt.bits(frames[0][0]), vt.bits(frames[1][0])) and frames[0][1] == frames[1][1] > 0
+
+
+def test_volume_mask_scene_from_dicom_files(tmp_path):
+    """The reference's VolumeMaskApp::OnStart from files (VolumeMaskApp.cpp:12-25): CT series, RTDOSE and RTSTRUCT are
+    read from (synthetic) DICOM, the mask comes from Create3DMask with the scene's post-processing options, and the
+    three-volume composite is rendered by the HIP path -- bit for bit the oracle's frame on the same arrays."""
+    import math
+
+    import dicom_writer as dw
+    n, nz = 40, 24
+    raw = synth.ct_phantom_raw(n)[:nz]  # (z, y, x)
+    ctd, dsd = tmp_path / "ct", tmp_path / "dose"
+    ctd.mkdir()
+    dsd.mkdir()
+    for k in range(nz):
+        # the reader fills x from Rows and y from Columns and streams the pixels in file order (DicomReader.cpp:181-182)
+        dw.write_slice(str(ctd / f"{k:03d}.dcm"), raw[k], rows=n, cols=n, instance=k + 1, position=(0.0, 0.0, 2.0 * k),
+                       spacing=(1.0, 1.0), thickness=2.0, largest=int(raw.max()), frame_uid="1.9.9")
+    dose = synth.dose_raw(16, 12, 8)
+    dw.write_slice(str(dsd / "dose.dcm"), dose, modality="RTDOSE", rows=16, cols=12, frames=8, bits=32, frame_uid="1.9.9")
+
+    def ring(cx, cy, r, z, m=180):
+        return [v for i in range(m) for v in (cx + r * math.cos(2 * math.pi * i / m), cy + r * math.sin(2 * math.pi * i / m), z)]
+
+    contours = [[ring(20, 20, 3, 2.0 * k) for k in range(3, 6)],                 # 1: never selected below
+                [ring(20, 19, 9, 2.0 * k) for k in range(6, 18)],                # 2 -> mask.r
+                [ring(12, 12, 2, 2.0)],                                          # 3
+                [[10.0, 26.0, 2.0 * k, 30.0, 27.5, 2.0 * k, 28.0, 33.0, 2.0 * k, 11.0, 31.0, 2.0 * k, 10.0, 26.0, 2.0 * k]
+                 for k in range(8, 14)],                                          # 4 -> mask.g (sparse: needs the lines)
+                [ring(5, 5, 1, 0.0)]]                                             # 5: the unreachable last one
+    dw.write_rtstruct(str(tmp_path / "rs.dcm"), contours, frame_uid="1.9.9")
+
+    ct = host.VolumeFile.from_dicom(str(ctd))
+    rt = host.VolumeFile.from_dicom(str(dsd))
+    rs = host.StructureFile.read(str(tmp_path / "rs.dcm"))
+    SF = host.StructureFile
+    mask = rs.create_3d_mask(ct, [2, 4, 0, 0], SF.RECONSTRUCT_BRESENHAM | SF.PROCESS_NON_DUPLICATES | SF.CLOSING | SF.FILL)
+    md = mask.data()
+    assert md[10, :, :, 0].sum() > 150 and md[10, :, :, 1].sum() > 60 and md[..., 2:].max() == 0
+
+    W, H = 120, 90
+    with host.Application(W, H, 0) as app:
+        app.OnStart(capi.VOLUME_MASK, [mask, rt, ct])
+        app.camera().SetOrbit(0.3, 0.8, 1.3)
+        app.OnUpdate()
+        app.OnRender()
+        frag, _, samples = app.ReadFrame()
+        u = hr.Uniforms.from_buffer_copy(bytes(app.uniforms()))
+        tfs = [(app.scene_opacity_tf(i).table(), app.scene_color_tf(i).table()) for i in (0, 1)]
+        ref, n_ref, _ = ob.render(capi.VOLUME_MASK, u, [mask.data(), rt.data(), ct.data()], tfs, W, H, nthreads=8)
+        assert np.array_equal(vt.bits(frag), vt.bits(ref)), float(np.max(np.abs(frag - ref)))
+        assert samples == n_ref and samples > 0
+        # the structures are visible: where the mask is set the RT table's colour is blended, so the frame differs from
+        # one rendered with an empty mask
+        empty = host.VolumeFile.from_vec4(np.zeros_like(md), 1)
+        app.OnStart(capi.VOLUME_MASK, [empty, rt, ct])
+        app.camera().SetOrbit(0.3, 0.8, 1.3)
+        app.OnUpdate()
+        app.OnRender()
+        frag0, _, _ = app.ReadFrame()
+        assert not np.array_equal(frag, frag0)

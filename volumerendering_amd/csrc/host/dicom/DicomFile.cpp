@@ -48,7 +48,109 @@ bool DicomFile::Load()
         m_Error = "unsupported transfer syntax " + ts + " (only uncompressed little endian)";
         return false;
     }
+    m_DatasetStart = pos;
+    m_ExplicitVr = explicitVr;
     return ParseDataset(pos, m_Bytes.size(), explicitVr, true, &pos);
+}
+
+namespace {
+// sequences of the RT Structure Set module (PS3.3 C.8.8.5 / C.8.8.6) and the ones nested in them
+bool known_sequence(Tag t)
+{
+    switch (t) {
+    case 0x30060010: case 0x30060012: case 0x30060014: case 0x30060016: case 0x30060020: case 0x30060030:
+    case 0x30060039: case 0x30060040: case 0x30060080: case 0x30060086: case 0x300600A0: case 0x300600B0:
+    case 0x00081140: case 0x00081155: case 0x00081115: case 0x0008114A:
+        return true;
+    default:
+        return false;
+    }
+}
+}  // namespace
+
+bool DicomFile::Walk(Visitor& visitor) const
+{
+    if (m_Bytes.empty() || m_DatasetStart == 0) return false;
+    size_t pos = m_DatasetStart;
+    std::string err;
+    return WalkDataset(&pos, m_Bytes.size(), false, visitor, &err);
+}
+
+// Elements from *pos to `end` (or to the item delimiter when inItem and the item has undefined length).
+bool DicomFile::WalkDataset(size_t* pos, size_t end, bool inItem, Visitor& visitor, std::string* err) const
+{
+    while (*pos + 8 <= end) {
+        const unsigned char* p = m_Bytes.data() + *pos;
+        const Tag tag = (static_cast<Tag>(rd16(p)) << 16) | rd16(p + 2);
+        if (tag == kItemDelim) {
+            *pos += 8;
+            return inItem;
+        }
+        if (tag == kSeqDelim) return false;  // a sequence delimiter is consumed by the sequence loop below
+        std::uint32_t length;
+        bool isSeq;
+        size_t header;
+        if (m_ExplicitVr) {
+            const unsigned char* vr = p + 4;
+            if (long_vr(vr)) {
+                if (*pos + 12 > end) return false;
+                length = rd32(p + 8);
+                header = 12;
+            } else {
+                length = rd16(p + 6);
+                header = 8;
+            }
+            isSeq = (vr[0] == 'S' && vr[1] == 'Q') || (length == kUndefined && tag != tags::kPixelData);
+        } else {
+            length = rd32(p + 4);
+            header = 8;
+            isSeq = (length == kUndefined && tag != tags::kPixelData) || known_sequence(tag);
+        }
+        *pos += header;
+        if (!isSeq) {
+            if (length == kUndefined || *pos + length > end) {
+                *err = "element runs past the end of the file";
+                return false;
+            }
+            visitor.Element(tag, reinterpret_cast<const char*>(m_Bytes.data() + *pos), length);
+            *pos += length;
+            continue;
+        }
+        const size_t seqEnd = length == kUndefined ? end : *pos + length;
+        if (seqEnd > end) return false;
+        visitor.BeginSequence(tag);
+        size_t index = 0;
+        bool closed = length != kUndefined;
+        while (*pos + 8 <= seqEnd) {
+            const unsigned char* q = m_Bytes.data() + *pos;
+            const Tag itag = (static_cast<Tag>(rd16(q)) << 16) | rd16(q + 2);
+            const std::uint32_t ilen = rd32(q + 4);
+            *pos += 8;
+            if (itag == kSeqDelim) {
+                closed = true;
+                break;
+            }
+            if (itag != kItem) {
+                *err = "malformed sequence";
+                return false;
+            }
+            visitor.BeginItem(tag, index);
+            if (ilen == kUndefined) {
+                if (!WalkDataset(pos, seqEnd, true, visitor, err)) return false;
+            } else {
+                size_t ipos = *pos;
+                const size_t iend = ipos + ilen;
+                if (iend > seqEnd) return false;
+                if (ipos < iend && !WalkDataset(&ipos, iend, false, visitor, err)) return false;
+                *pos = iend;
+            }
+            visitor.EndItem(tag, index);
+            ++index;
+        }
+        if (!closed) return false;
+        visitor.EndSequence(tag);
+    }
+    return !inItem;  // an item of undefined length must end with its delimiter
 }
 
 // Parses elements from pos; at top level it stops after the meta group when asked to switch syntax (group > 0002

@@ -1,7 +1,9 @@
 // DicomFile -- minimal DICOM Part 10 reader: what the volume path needs from the `dcm` library the reference
 // links (an un-vendored fork, .gitmodules:21-24; call sites DicomReader.cpp:70-72,177-213,237,245).  Supports the
 // uncompressed little-endian transfer syntaxes (Implicit VR 1.2.840.10008.1.2, Explicit VR 1.2.840.10008.1.2.1);
-// sequences (defined or undefined length) are skipped, encapsulated pixel data is rejected.
+// the Get* accessors see the top-level, non-sequence elements (sequences are skipped over), Walk() visits every
+// element in file order including those nested in sequences (what the reference's dcm::Visitor does for RTSTRUCT
+// files, StructVisitor.h:18-121); encapsulated pixel data is rejected.
 #pragma once
 #include <cstdint>
 #include <map>
@@ -30,6 +32,17 @@ constexpr Tag kLargestPixelValue = 0x00280107;
 constexpr Tag kPixelData = 0x7FE00010;
 }  // namespace tags
 
+// Walk() callbacks, in file order.  Element values are the raw bytes (text VRs: trailing padding still attached).
+class Visitor {
+public:
+    virtual ~Visitor() = default;
+    virtual void Element(Tag /*tag*/, const char* /*bytes*/, size_t /*length*/) {}
+    virtual void BeginSequence(Tag /*tag*/) {}
+    virtual void BeginItem(Tag /*sequence*/, size_t /*index*/) {}
+    virtual void EndItem(Tag /*sequence*/, size_t /*index*/) {}
+    virtual void EndSequence(Tag /*tag*/) {}
+};
+
 class DicomFile {
 public:
     explicit DicomFile(std::string path) : m_Path(std::move(path)) {}
@@ -46,6 +59,9 @@ public:
     bool GetUint16(Tag tag, std::uint16_t* value) const;
     bool GetUint16Array(Tag tag, std::vector<std::uint16_t>* values) const;
     bool GetUint32Array(Tag tag, std::vector<std::uint32_t>* values) const;
+    // Visits the main data set (after Load()).  In Implicit VR a sequence of DEFINED length cannot be told from a
+    // plain element without a dictionary: the RT Structure Set sequences are known, others are reported as elements.
+    bool Walk(Visitor& visitor) const;
 
 private:
     struct Element {
@@ -54,10 +70,13 @@ private:
     };
     bool ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLevel, size_t* stop);
     bool SkipSequence(size_t* pos, size_t end, std::uint32_t length, bool explicitVr);
+    bool WalkDataset(size_t* pos, size_t end, bool inItem, Visitor& visitor, std::string* err) const;
 
     std::string m_Path, m_Error;
     std::vector<unsigned char> m_Bytes;
     std::map<Tag, Element> m_Elements;  // top-level, non-sequence elements
+    size_t m_DatasetStart = 0;          // first byte behind the file meta group
+    bool m_ExplicitVr = true;           // of the main data set
 };
 
 }  // namespace med::dcmlite

@@ -3,6 +3,9 @@
 #include <array>
 #include <cstdint>
 #include <string>
+#include <vector>
+
+#include "../vrm.h"
 
 namespace med {
 
@@ -30,6 +33,20 @@ struct DicomVolumeParams : public DicomBaseParams {
     std::array<double, 6> ImageOrientationPatient{0.0};    // (0020,0037)
     std::array<double, 2> PixelSpacing{0.0};               // (0028,0030) row / column spacing
     std::string MainAxis{};
+};
+
+// RTSTRUCT (DicomParams.h:44-66)
+struct DicomStructParams : public DicomBaseParams {
+    DicomStructParams() : DicomBaseParams(DicomModality::RTSTRUCT) {}
+    struct StructureSetROI {      // an item of (3006,0020) Structure Set ROI Sequence
+        int Number = 0;           // (3006,0022) ROI Number
+        std::string Name{};       // (3006,0026) ROI Name
+        std::string AlgorithmType{};  // (3006,0036) ROI Generation Algorithm
+    };
+    std::string Label{};  // (3006,0002) Structure Set Label
+    std::string Name{};   // (3006,0004) Structure Set Name
+    std::vector<StructureSetROI> StructureSetROISequence{};
+    std::vector<vrm::vec3> DisplayColors{};  // (3006,002A) ROI Display Color, / 255
 };
 
 }  // namespace med

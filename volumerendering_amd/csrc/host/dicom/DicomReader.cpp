@@ -27,10 +27,91 @@ std::array<T, N> ParseStringToNumArr(const std::string& str)
     return numbers;
 }
 template std::array<int, 1> ParseStringToNumArr<int, 1>(const std::string&);
+template std::array<int, 3> ParseStringToNumArr<int, 3>(const std::string&);
 template std::array<double, 1> ParseStringToNumArr<double, 1>(const std::string&);
 template std::array<double, 2> ParseStringToNumArr<double, 2>(const std::string&);
 template std::array<double, 3> ParseStringToNumArr<double, 3>(const std::string&);
 template std::array<double, 6> ParseStringToNumArr<double, 6>(const std::string&);
+
+std::vector<float> ParseContours(const std::string& str)
+{
+    std::vector<float> res;
+    std::stringstream ss(str);
+    std::string temp;
+    while (std::getline(ss, temp, '\\')) {
+        try {
+            res.push_back(std::stof(temp));
+        } catch (const std::exception&) {  // "Parsing contour data failed!"
+        }
+    }
+    return res;
+}
+
+namespace {
+// What the reference's StructVisitor collects while the dcm library walks the data set (StructVisitor.h:22-121):
+// every item of (3006,0039) ROI Contour Sequence opens a contour, every (3006,0050) Contour Data below it adds a
+// polygon; every item of (3006,0020) Structure Set ROI Sequence opens an ROI description.
+class StructCollector : public dcmlite::Visitor {
+public:
+    void BeginItem(dcmlite::Tag sequence, size_t) override
+    {
+        if (sequence == 0x30060039) ContourData.emplace_back();
+        else if (sequence == 0x30060020) Params.StructureSetROISequence.emplace_back();
+    }
+    void Element(dcmlite::Tag tag, const char* bytes, size_t length) override
+    {
+        auto text = [&] {
+            size_t n = length;
+            while (n > 0 && (bytes[n - 1] == ' ' || bytes[n - 1] == '\0')) --n;
+            return std::string(bytes, n);
+        };
+        switch (tag) {
+        case 0x30060050:  // Contour Data
+            if (!ContourData.empty()) ContourData.back().push_back(ParseContours(text()));
+            break;
+        case 0x3006002A: {  // ROI Display Color
+            const auto d = ParseStringToNumArr<int, 3>(text());
+            constexpr float factor = 1 / 255.0f;
+            Params.DisplayColors.push_back({d[0] * factor, d[1] * factor, d[2] * factor});
+            break;
+        }
+        case 0x30060022:  // ROI Number
+            if (!Params.StructureSetROISequence.empty()) Params.StructureSetROISequence.back().Number = ParseStringToNumArr<int, 1>(text())[0];
+            break;
+        case 0x30060026:  // ROI Name
+            if (!Params.StructureSetROISequence.empty()) Params.StructureSetROISequence.back().Name = text();
+            break;
+        case 0x30060036:  // ROI Generation Algorithm
+            if (!Params.StructureSetROISequence.empty()) Params.StructureSetROISequence.back().AlgorithmType = text();
+            break;
+        case 0x00200052: Params.FrameOfReference = text(); break;  // wherever it occurs; the last one wins
+        case 0x30060004: Params.Name = text(); break;
+        case 0x30060002: Params.Label = text(); break;
+        default: break;
+        }
+    }
+    DicomStructParams Params;
+    std::vector<std::vector<std::vector<float>>> ContourData;
+};
+}  // namespace
+
+std::shared_ptr<StructureFileDcm> DicomReader::ReadStructFile(std::filesystem::path name)
+{
+    if (std::filesystem::is_directory(name)) {
+        std::vector<std::filesystem::path> files;
+        for (const auto& e : std::filesystem::directory_iterator(name))
+            if (e.path().extension().string() == ".dcm") files.push_back(e.path());
+        if (files.size() != 1) return nullptr;  // "No structure files found!" / "Multiple contour files are not allowed!"
+        name = files[0];
+    }
+    if (!IsDicomFile(name)) return nullptr;
+    DicomFile f(name.string());
+    if (!f.Load()) return nullptr;
+    if (ResolveModality(f.GetString(tags::kModality)) != DicomModality::RTSTRUCT) return nullptr;  // "Not a valid struct file"
+    StructCollector visitor;
+    if (!f.Walk(visitor)) return nullptr;
+    return std::make_shared<StructureFileDcm>(name, visitor.Params, visitor.ContourData);
+}
 
 std::shared_ptr<VolumeFileDcm> DicomReader::ReadVolumeFile(std::filesystem::path name)
 {

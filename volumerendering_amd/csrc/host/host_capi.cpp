@@ -98,6 +98,83 @@ int vrh_dicom_compare(void* a, void* b, int which)
     return which == 0 ? da->CompareFrameOfReference(*db) : da->CompareOrientation(*db);
 }
 int vrh_dicom_modality(const char* path) { VRH_TRY(0, { return (int)DicomReader::CheckModality(path); }) }
+
+// ---- RTSTRUCT ---------------------------------------------------------------------------------------------------
+void* vrh_struct_read(const char* path)
+{
+    VRH_TRY(nullptr, {
+        auto s = DicomReader::ReadStructFile(path);
+        return s ? new std::shared_ptr<StructureFileDcm>(s) : nullptr;
+    })
+}
+void* vrh_struct_from_contours(const char* frame_of_reference, const float* points, const int* polygon_sizes,
+                               const int* polygons_per_contour, int n_contours)
+{
+    try {
+        DicomStructParams p;
+        p.FrameOfReference = frame_of_reference;
+        std::vector<std::vector<std::vector<float>>> data((size_t)n_contours);
+        size_t poly = 0, off = 0;
+        for (int c = 0; c < n_contours; ++c)
+            for (int k = 0; k < polygons_per_contour[c]; ++k) {
+                const int n = polygon_sizes[poly++];
+                data[(size_t)c].emplace_back(points + off, points + off + n);
+                off += (size_t)n;
+            }
+        return new std::shared_ptr<StructureFileDcm>(std::make_shared<StructureFileDcm>("", p, data));
+    } catch (...) {
+        return nullptr;
+    }
+}
+void vrh_struct_free(void* s) { delete static_cast<std::shared_ptr<StructureFileDcm>*>(s); }
+int vrh_struct_contour_count(void* s) { return (int)(*static_cast<std::shared_ptr<StructureFileDcm>*>(s))->GetContourData().size(); }
+int vrh_struct_polygon_count(void* s, int contour)
+{
+    const auto& d = (*static_cast<std::shared_ptr<StructureFileDcm>*>(s))->GetContourData();
+    return contour >= 0 && (size_t)contour < d.size() ? (int)d[(size_t)contour].size() : -1;
+}
+int vrh_struct_polygon(void* s, int contour, int polygon, float* out, int capacity)
+{
+    const auto& d = (*static_cast<std::shared_ptr<StructureFileDcm>*>(s))->GetContourData();
+    if (contour < 0 || (size_t)contour >= d.size() || polygon < 0 || (size_t)polygon >= d[(size_t)contour].size()) return -1;
+    const auto& p = d[(size_t)contour][(size_t)polygon];
+    for (int i = 0; i < capacity && (size_t)i < p.size(); ++i) out[i] = p[(size_t)i];
+    return (int)p.size();
+}
+// text: "label\nname\nframe of reference\n" then one line "number\tname\talgorithm" per ROI; colors: rgb per ROI
+int vrh_struct_info(void* s, char* text, int len, float* colors, int max_colors)
+{
+    VRH_TRY(-1, {
+        const DicomStructParams p = (*static_cast<std::shared_ptr<StructureFileDcm>*>(s))->GetStructParams();
+        std::string t = p.Label + "\n" + p.Name + "\n" + p.FrameOfReference + "\n";
+        for (const auto& r : p.StructureSetROISequence) t += std::to_string(r.Number) + "\t" + r.Name + "\t" + r.AlgorithmType + "\n";
+        std::strncpy(text, t.c_str(), (size_t)len - 1);
+        text[len - 1] = 0;
+        int n = 0;
+        for (const auto& c : p.DisplayColors) {
+            if (n >= max_colors) break;
+            colors[3 * n] = c.x;
+            colors[3 * n + 1] = c.y;
+            colors[3 * n + 2] = c.z;
+            ++n;
+        }
+        return (int)p.DisplayColors.size();
+    })
+}
+// StructureFileDcm::Create3DMask; `volume` must come from vrh_volume_from_dicom.  NULL when the reference returns nullptr.
+void* vrh_struct_create_mask(void* s, void* volume, const int ids[4], unsigned post_process)
+{
+    try {
+        auto* vh = static_cast<VolumeHandle*>(volume);
+        if (!vh->dcm) return nullptr;
+        const std::array<int, 4> four{ids[0], ids[1], ids[2], ids[3]};
+        auto m = (*static_cast<std::shared_ptr<StructureFileDcm>*>(s))->Create3DMask(*vh->dcm, four, static_cast<ContourPostProcess>(post_process));
+        if (!m) return nullptr;
+        return new VolumeHandle{m, m};
+    } catch (...) {
+        return nullptr;
+    }
+}
 void vrh_volume_free(void* h) { delete static_cast<VolumeHandle*>(h); }
 void vrh_volume_normalize(void* h, int value) { static_cast<VolumeHandle*>(h)->v->NormalizeData(value); }
 void vrh_volume_gradient(void* h, int norm01) { static_cast<VolumeHandle*>(h)->v->PreComputeGradient(norm01 != 0); }

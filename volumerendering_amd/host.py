@@ -31,6 +31,10 @@ def load() -> C.CDLL:
         "vrh_volume_from_dicom": (vp, [C.c_char_p, C.c_char_p, i32]), "vrh_dicom_params": (i32, [vp, vp, C.c_char_p, C.c_char_p, i32]),
         "vrh_dicom_transform": (None, [vp, i32, vp, vp]), "vrh_dicom_compare": (i32, [vp, vp, i32]),
         "vrh_dicom_modality": (i32, [C.c_char_p]), "vrh_volume_free": (None, [vp]),
+        "vrh_struct_read": (vp, [C.c_char_p]), "vrh_struct_from_contours": (vp, [C.c_char_p, vp, vp, vp, i32]),
+        "vrh_struct_free": (None, [vp]), "vrh_struct_contour_count": (i32, [vp]), "vrh_struct_polygon_count": (i32, [vp, i32]),
+        "vrh_struct_polygon": (i32, [vp, i32, i32, vp, i32]), "vrh_struct_info": (i32, [vp, C.c_char_p, i32, vp, i32]),
+        "vrh_struct_create_mask": (vp, [vp, vp, vp, C.c_uint]),
         "vrh_volume_normalize": (None, [vp, i32]), "vrh_volume_gradient": (None, [vp, i32]),
         "vrh_volume_average_gradient": (None, [vp, i32]), "vrh_volume_data": (vp, [vp]),
         "vrh_volume_max_number": (u64, [vp]), "vrh_volume_data_range": (u64, [vp]),
@@ -185,6 +189,71 @@ class VolumeFile:
         ptr = self.lib.vrh_volume_data(self.h)
         buf = (C.c_float * (nx * ny * nz * 4)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.float32).reshape(nz, ny, nx, 4)
+
+
+class StructureFile:
+    """med::StructureFileDcm (csrc/host/dicom/StructureFileDcm.h): an RTSTRUCT file's contours + Create3DMask."""
+    IGNORE, NEAREST_NEIGHBOUR, RECONSTRUCT_BRESENHAM, CLOSING, FILL, PROCESS_NON_DUPLICATES = 1, 2, 4, 8, 16, 32
+
+    def __init__(self, handle):
+        self.lib = load()
+        self.h = handle
+
+    @classmethod
+    def read(cls, path: str):
+        """med::DicomReader::ReadStructFile; None where the reference returns nullptr."""
+        h = load().vrh_struct_read(path.encode())
+        return cls(h) if h else None
+
+    @classmethod
+    def from_contours(cls, contours, frame_of_reference: str = ""):
+        """contours[c][k] = flat x y z x y z ... of polygon k of contour c."""
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float32).ravel() for c in contours for p in c]
+                                                  or [np.zeros(0, np.float32)]), dtype=np.float32)
+        sizes = np.asarray([len(np.asarray(p).ravel()) for c in contours for p in c], dtype=np.int32)
+        per = np.asarray([len(c) for c in contours], dtype=np.int32)
+        return cls(load().vrh_struct_from_contours(frame_of_reference.encode(), pts.ctypes.data, sizes.ctypes.data,
+                                                   per.ctypes.data, len(contours)))
+
+    def contours(self):
+        out = []
+        for c in range(self.lib.vrh_struct_contour_count(self.h)):
+            polys = []
+            for k in range(self.lib.vrh_struct_polygon_count(self.h, c)):
+                n = self.lib.vrh_struct_polygon(self.h, c, k, None, 0)
+                a = np.zeros(n, dtype=np.float32)
+                self.lib.vrh_struct_polygon(self.h, c, k, a.ctypes.data, n)
+                polys.append(a)
+            out.append(polys)
+        return out
+
+    def info(self) -> dict:
+        text = C.create_string_buffer(1 << 16)
+        colors = np.zeros((256, 3), dtype=np.float32)
+        n = self.lib.vrh_struct_info(self.h, text, 1 << 16, colors.ctypes.data, 256)
+        lines = text.value.decode().split("\n")
+        rois = [dict(zip(("Number", "Name", "AlgorithmType"), l.split("\t"))) for l in lines[3:] if l]
+        for r in rois:
+            r["Number"] = int(r["Number"])
+        return dict(Label=lines[0], Name=lines[1], FrameOfReference=lines[2], StructureSetROISequence=rois,
+                    DisplayColors=colors[:max(n, 0)].copy())
+
+    def create_3d_mask(self, reference: "VolumeFile", contour_ids, post_process: int):
+        """Create3DMask(other, contourIDs[4], postProcess) -> VolumeFile (x, y, z, w = the selected contours) or None."""
+        ids = (C.c_int * 4)(*(list(contour_ids) + [0, 0, 0, 0])[:4])
+        h = self.lib.vrh_struct_create_mask(self.h, reference.h, ids, post_process)
+        return VolumeFile(h) if h else None
+
+    def close(self):
+        if self.h:
+            self.lib.vrh_struct_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _TF:
