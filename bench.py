@@ -33,7 +33,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 # per-composited-sample algorithmic bytes: the f32 footprint of one trilinear cell
-BYTES_PER_SAMPLE = {"BASIC": 32, "LIGHT": 128, "VOLUME_MASK": 288, "THREE_FILES": 64, "MULTI_CTRT": 160, "TF_CALIB": 48}
+BYTES_PER_SAMPLE = {"BASIC": 32, "LIGHT": 128, "VOLUME_MASK": 288, "THREE_FILES": 64, "MULTI_CTRT": 160, "TF_CALIB": 48,
+                    "ILLUSTRATIVE": 160}
 
 # which kernel a resolved flavour runs (include/vr.h, vr_set_kernel_flavour)
 KERNEL_OF_FLAVOUR = {1: "march_kernel (no skipping)", 2: "march_wtb_light_kernel", 3: "march_wtb_light_kernel",

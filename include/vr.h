@@ -42,7 +42,7 @@ typedef enum vr_status {
     VR_ERR_OOM = -5
 } vr_status;
 
-/* One value per live fragment shader of the reference. */
+/* One value per fragment shader of the reference. */
 typedef enum vr_variant {
     VR_VARIANT_BASIC = 0,       /* App/shaders/BasicVolumeApp.wgsl:113-188   unlit, cut-off dst.a <= 0.95 */
     VR_VARIANT_LIGHT = 1,       /* App/shaders/BasicVolLightApp.wgsl:151-237 lit,   cut-off dst.a <  1.0  */
@@ -50,7 +50,11 @@ typedef enum vr_variant {
     VR_VARIANT_THREE_FILES = 3, /* App/shaders/ThreeFilesApp.wgsl:170-272    CT/RT colour mix             */
     VR_VARIANT_MULTI_CTRT = 4,  /* App/shaders/MultiCTRTApp.wgsl:163-259     CT/RT mix + shade + |g| opacity */
     VR_VARIANT_TF_CALIB = 5,    /* App/shaders/TFCalibrationApp.wgsl:114-197 CT + nearest-sampled mask     */
-    VR_VARIANT_COUNT = 6
+    /* App/shaders/MutliCTRTIllustrative.wgsl:227-313: MULTI_CTRT with the context-preserving opacity
+     * opacityCT * pow(|g|, pow(5 s (1 - d) (1 - dst.a), 0.8)); slots as MULTI_CTRT, reads camera_pos.  The reference
+     * compiles this module next to MultiCTRTApp.wgsl but never attaches it (MutliCTRTApp.cpp:112-119). */
+    VR_VARIANT_ILLUSTRATIVE = 6,
+    VR_VARIANT_COUNT = 7
 } vr_variant;
 
 #define VR_MAX_VOLUMES 3

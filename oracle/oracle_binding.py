@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvr_oracle.so")
 
-BASIC, LIGHT, VOLUME_MASK, THREE_FILES, MULTI_CTRT, TF_CALIB = range(6)
+BASIC, LIGHT, VOLUME_MASK, THREE_FILES, MULTI_CTRT, TF_CALIB, ILLUSTRATIVE = range(7)
 
 
 class Volume(C.Structure):
@@ -61,6 +61,8 @@ def load() -> C.CDLL:
     lib.vro_lerp_vec4.restype = None
     lib.vro_jitter.argtypes = [C.c_float, C.c_float]
     lib.vro_jitter.restype = C.c_float
+    lib.vro_pow.argtypes = [C.c_float, C.c_float]
+    lib.vro_pow.restype = C.c_float
     _lib = lib
     return lib
 
@@ -162,3 +164,8 @@ def lerp_vec4(x0, x1, fx0, fx1):
 
 def jitter(x, y):
     return float(load().vro_jitter(x, y))
+
+
+def pow_rep(x, y):
+    """The oracle's reproducible WGSL pow (exp2(y * log2(x)) through f64)."""
+    return float(load().vro_pow(x, y))

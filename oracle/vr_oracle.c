@@ -99,6 +99,77 @@ float vro_jitter(float x, float y)
     return v - floorf(v);
 }
 
+/* ------------------------------------------------------------------ deterministic pow (illustrative shader) */
+
+static double log2_d(double x) /* x > 0, finite, normal (every positive float is a normal double) */
+{
+    uint64_t b;
+    memcpy(&b, &x, 8);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m;
+    memcpy(&m, &b, 8); /* [1, 2) */
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
+    double s = (m - 1.0) / (m + 1.0); /* log(m) = 2 atanh(s), |s| <= 0.1716 */
+    double s2 = s * s;
+    double t = s2 * (1.0 / 23.0);
+    t = s2 * (t + (1.0 / 21.0));
+    t = s2 * (t + (1.0 / 19.0));
+    t = s2 * (t + (1.0 / 17.0));
+    t = s2 * (t + (1.0 / 15.0));
+    t = s2 * (t + (1.0 / 13.0));
+    t = s2 * (t + (1.0 / 11.0));
+    t = s2 * (t + (1.0 / 9.0));
+    t = s2 * (t + (1.0 / 7.0));
+    t = s2 * (t + (1.0 / 5.0));
+    t = s2 * (t + (1.0 / 3.0));
+    double ln = (2.0 * s) * (t + 1.0);
+    return (double)e + ln * 1.4426950408889634; /* 1 / ln 2 */
+}
+
+static double exp2_d(double t) /* finite t in (-1100, 1024) */
+{
+    double n = rint(t);
+    double z = (t - n) * 0.6931471805599453; /* ln 2; |z| <= 0.3466 */
+    double r = z * (1.0 / 87178291200.0);
+    r = z * (r + (1.0 / 6227020800.0));
+    r = z * (r + (1.0 / 479001600.0));
+    r = z * (r + (1.0 / 39916800.0));
+    r = z * (r + (1.0 / 3628800.0));
+    r = z * (r + (1.0 / 362880.0));
+    r = z * (r + (1.0 / 40320.0));
+    r = z * (r + (1.0 / 5040.0));
+    r = z * (r + (1.0 / 720.0));
+    r = z * (r + (1.0 / 120.0));
+    r = z * (r + (1.0 / 24.0));
+    r = z * (r + (1.0 / 6.0));
+    r = z * (r + 0.5);
+    r = z * (r + 1.0);
+    r = r + 1.0;
+    int k = (int)n;
+    if (k < -1022) return 0.0; /* far below the smallest float */
+    uint64_t b = (uint64_t)(k + 1023) << 52;
+    double p2;
+    memcpy(&p2, &b, 8);
+    return r * p2;
+}
+
+float vro_pow(float x, float y)
+{
+    double lx;
+    if (x != x || x < 0.0f) lx = NAN;
+    else if (x == 0.0f) lx = -INFINITY;
+    else if (x == INFINITY) lx = INFINITY;
+    else lx = log2_d((double)x);
+    double t = (double)y * lx; /* 0 * inf -> NaN, as exp2(y * log2(x)) gives */
+    double r;
+    if (t != t) r = NAN;
+    else if (t >= 1024.0) r = INFINITY;
+    else if (t <= -1100.0) r = 0.0;
+    else r = exp2_d(t);
+    return (float)r;
+}
+
 /* ------------------------------------------------------------------ samplers (Sampler.cpp:9-24) */
 
 /* 3-D linear, clamp-to-edge, single mip (Texture.cpp:48); texel (i,j,k) at vec4[(k*ny + j)*nx + i]
@@ -315,8 +386,8 @@ uint32_t vro_shade_pixel(int variant, const vro_uniforms* u, const vro_volume* v
         for (int c = 0; c < 3; ++c) p[c] = p[c] + (dir[c] * step_size) * j;
     }
     float step[3] = { dir[0] * step_size, dir[1] * step_size, dir[2] * step_size };
-    if (variant == VRO_MULTI_CTRT) {
-        /* CalculateWorldStep AFTER the override: MultiCTRTApp.wgsl:213-214, 154-160 */
+    if (variant == VRO_MULTI_CTRT || variant == VRO_ILLUSTRATIVE) {
+        /* CalculateWorldStep AFTER the override: MultiCTRTApp.wgsl:213-214, 154-160 (MutliCTRTIllustrative.wgsl:262-263) */
         world_step[0] = dir[0] * (step_size * 1.0f);
         world_step[1] = dir[1] * (step_size * 1.0f);
         world_step[2] = dir[2] * (step_size * 0.7f);
@@ -415,6 +486,40 @@ uint32_t vro_shade_pixel(int variant, const vro_uniforms* u, const vro_volume* v
                 shade(N, wc, lp, ldif, lamb, 3.5f, 0.5f, s); /* BlinnPhong :129-139 */
                 col[0] *= s[0]; col[1] *= s[1]; col[2] *= s[2];
                 float opacity = o_ct * length3(ct); /* GradinetMagnitudeOpacityModulation :148-151 */
+                front_to_back_blend(col, opacity, dst);
+                ++blends;
+            }
+        } break;
+        case VRO_ILLUSTRATIVE: { /* MutliCTRTIllustrative.wgsl:271-310; vols / tfs as MULTI_CTRT */
+            float ct[4], rt[4], cct[3], crt[3], col[3];
+            tex3_linear(&vols[0], p, ct);
+            tex3_linear(&vols[1], p, rt);
+            float o_ct = tf_opacity(&tfs[0], ct[3]);
+            tf_color(&tfs[0], ct[3], cct);
+            float o_rt = tf_opacity(&tfs[1], rt[3]);
+            tf_color(&tfs[1], rt[3], crt);
+            if (in_sample_coords(u, p) && dst[3] <= 0.95f) {
+                static const float lp[3] = { 0.0f, -5.0f, 0.0f };
+                float N[3], s3[3];
+                for (int c = 0; c < 3; ++c) col[c] = cct[c] * (1.0f - o_rt) + crt[c] * o_rt;
+                normalize3(ct, N);
+                shade(N, wc, lp, ldif, lamb, 3.5f, 0.5f, s3); /* BlinnPhong :132-143 */
+                col[0] *= s3[0]; col[1] *= s3[1]; col[2] *= s3[2];
+                /* IllustrativeContextPreservingOpacity :158-186 (the texture-space distance option, :182) */
+                float Lv[3] = { lp[0] - wc[0], lp[1] - wc[1], lp[2] - wc[2] }, L[3];
+                normalize3(Lv, L);
+                float Vv[3] = { u->camera_pos[0] - wc[0], u->camera_pos[1] - wc[1], u->camera_pos[2] - wc[2] }, V[3];
+                normalize3(Vv, V);
+                float Hv[3] = { V[0] + L[0], V[1] + L[1], V[2] + L[2] }, Hn[3];
+                normalize3(Hv, Hn);
+                float Lg[3] = { L[0] * ct[0], L[1] * ct[1], L[2] * ct[2] };
+                float Hg[3] = { Hn[0] * ct[0], Hn[1] * ct[1], Hn[2] * ct[2] };
+                float s = (0.5f + 2.5f * length3(Lg)) + 1.0f * vro_pow(length3(Hg), 1.0f);
+                float dv[3] = { p[0] - start[0], p[1] - start[1], p[2] - start[2] };
+                float dist = length3(dv);
+                if (dist > 1.0f) dist = 1.0f;
+                float inner = vro_pow(((5.0f * s) * (1.0f - dist)) * (1.0f - dst[3]), 0.8f);
+                float opacity = o_ct * vro_pow(length3(ct), inner);
                 front_to_back_blend(col, opacity, dst);
                 ++blends;
             }

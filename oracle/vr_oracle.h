@@ -32,7 +32,8 @@ typedef struct vro_uniforms {
 typedef struct vro_volume { const float* vec4; int32_t nx, ny, nz; } vro_volume; /* x fastest, 4 floats/voxel */
 typedef struct vro_tf { const float* opacity; const float* color_rgba; int32_t res; int32_t res_color; } vro_tf; /* res = opacity table */
 
-enum { VRO_BASIC = 0, VRO_LIGHT = 1, VRO_VOLUME_MASK = 2, VRO_THREE_FILES = 3, VRO_MULTI_CTRT = 4, VRO_TF_CALIB = 5 };
+enum { VRO_BASIC = 0, VRO_LIGHT = 1, VRO_VOLUME_MASK = 2, VRO_THREE_FILES = 3, VRO_MULTI_CTRT = 4, VRO_TF_CALIB = 5,
+       VRO_ILLUSTRATIVE = 6 /* MutliCTRTIllustrative.wgsl (compiled but never attached by the reference) */ };
 
 /* Ray set-up for one pixel (restates rayCoords.wgsl + the vertex stage + rasteriser).
  * Returns 1 when the pixel has a fragment; start/end are uvw, world0 the world-space entry. */
@@ -64,6 +65,9 @@ void vro_lerp_vec4(int x0, int x1, const float fx0[4], const float fx1[4], float
 
 /* jitter() helper exposed for tests. */
 float vro_jitter(float x, float y);
+/* WGSL pow(x, y) = exp2(y * log2(x)) (what the reference's HLSL back end emits), evaluated through f64 with a fixed
+ * operation sequence so that the kernel can reproduce it bit for bit; x < 0 -> NaN, pow(0, 0) -> NaN. */
+float vro_pow(float x, float y);
 
 #ifdef __cplusplus
 }

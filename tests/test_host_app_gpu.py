@@ -22,14 +22,14 @@ def scene_inputs(variant, n):
         return [mask, dose, ct]
     if variant == capi.THREE_FILES:
         return [ct, dose, mask]
-    if variant == capi.MULTI_CTRT:
+    if variant in (capi.MULTI_CTRT, capi.ILLUSTRATIVE):
         return [ct, dose]
     unfilled = synth.mask_vec4(n).copy()
     unfilled[1:-1, 1:-1, 1:-1, 0] *= 0  # keep only a shell, as a contour mask without FILL would
     return [ct, mask, host.VolumeFile.from_vec4(unfilled, 1)]
 
 
-@pytest.mark.parametrize("variant", range(6))
+@pytest.mark.parametrize("variant", range(7))
 def test_scene_through_host_surface(variant):
     W, H, n = 112, 72, 20
     vols = scene_inputs(variant, n)
@@ -40,7 +40,7 @@ def test_scene_through_host_surface(variant):
         if variant == capi.THREE_FILES:
             # the reference leaves this scene on the Application defaults (0.01 / 200) with UN-normalised data
             assert app.stepping() == (200, pytest.approx(0.01))
-        elif variant in (capi.MULTI_CTRT, capi.TF_CALIB):
+        elif variant in (capi.MULTI_CTRT, capi.TF_CALIB, capi.ILLUSTRATIVE):
             assert app.stepping()[0] == 200  # these scenes never call ComputeRecommendedSteppingParams
         else:
             assert app.stepping()[0] == int(np.sqrt(3) * n)
@@ -53,10 +53,13 @@ def test_scene_through_host_surface(variant):
         else:
             volumes = [v.data() for v in vols]
         tfs = [(app.scene_opacity_tf(0).table(), app.scene_color_tf(0).table())]
-        if variant in (capi.VOLUME_MASK, capi.THREE_FILES, capi.MULTI_CTRT):
+        if variant in (capi.VOLUME_MASK, capi.THREE_FILES, capi.MULTI_CTRT, capi.ILLUSTRATIVE):
             tfs.append((app.scene_opacity_tf(1).table(), app.scene_color_tf(1).table()))
         ref, n_ref, _ = ob.render(variant, u, volumes, tfs, W, H, nthreads=8)
-        assert np.array_equal(vt.bits(frag), vt.bits(ref)), float(np.max(np.abs(frag - ref)))
+        fin = np.isfinite(ref)  # (the illustrative shader's pow(0, 0) is NaN on both sides)
+        assert fin.all() or variant == capi.ILLUSTRATIVE
+        assert np.array_equal(np.isnan(frag), np.isnan(ref))
+        assert np.array_equal(vt.bits(frag)[fin], vt.bits(ref)[fin]), float(np.nanmax(np.abs(frag - ref)))
         assert samples == n_ref and samples > 0
         assert np.array_equal(bgra, ob.present(ref))
 

@@ -224,3 +224,21 @@ def test_present_blend_over_white():
     b = 0.6 * 0.5 + 0.5
     a = 0.5 * 0.5 + 0.5
     assert out[2].tolist() == [int(b * 255 + 0.5), int(g * 255 + 0.5), int(r * 255 + 0.5), int(a * 255 + 0.5)]
+
+
+def test_reproducible_pow_is_a_correctly_rounded_pow():
+    """vro_pow = exp2(y * log2(x)) through f64 (fixed operation sequence, shared with the kernel): on ordinary arguments
+    it equals the correctly rounded f32 power; the edge cases follow exp2(y log2 x) literally, as the reference's HLSL
+    back end does."""
+    import math
+    rng = np.random.default_rng(5)
+    for _ in range(5000):
+        x = np.float32(10.0 ** rng.uniform(-6, 3))
+        y = np.float32(rng.uniform(-6, 6))
+        want = math.pow(float(x), float(y))
+        if 1e-37 < want < 3e38:
+            assert np.float32(ob.pow_rep(float(x), float(y))) == np.float32(want), (x, y)
+    assert ob.pow_rep(3.0, 1.0) == 3.0 and ob.pow_rep(2.0, 10.0) == 1024.0 and ob.pow_rep(0.25, 0.5) == 0.5
+    assert ob.pow_rep(0.0, 0.8) == 0.0 and ob.pow_rep(5.0, 0.0) == 1.0 and ob.pow_rep(1.0, 123.0) == 1.0
+    assert math.isnan(ob.pow_rep(0.0, 0.0)) and math.isnan(ob.pow_rep(-1.0, 2.0)) and math.isnan(ob.pow_rep(float("nan"), 1.0))
+    assert ob.pow_rep(float("inf"), -1.0) == 0.0 and ob.pow_rep(10.0, 60.0) == float("inf") and ob.pow_rep(10.0, -60.0) == 0.0

@@ -51,7 +51,7 @@ def scene(variant, n=16, tf_res=64, thin=False):
         return [hr.mask_vec4(n), dose_volume(), make_volume("phantom", n, norm01=True, grad_first=True)], [tf0, tf1]
     if variant == capi.THREE_FILES:
         return [make_volume("phantom", n), dose_volume(), hr.mask_vec4(n)], [tf0, tf1]
-    if variant == capi.MULTI_CTRT:
+    if variant in (capi.MULTI_CTRT, capi.ILLUSTRATIVE):
         return [make_volume("phantom", n, norm01=True, grad_first=True), dose_volume()], [tf0, tf1]
     if variant == capi.TF_CALIB:
         return [make_volume("phantom", n), hr.mask_vec4(n)], [tf0]

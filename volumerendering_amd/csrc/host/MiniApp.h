@@ -120,12 +120,16 @@ public:
     MultiCTRTApp(VolumePtr ct, VolumePtr rt) : p_Ct(std::move(ct)), p_Rt(std::move(rt)) {}
     void OnStart(vr_ctx* ctx) override;
     void OnUpdate() override;
-    int Variant() const override { return VR_VARIANT_MULTI_CTRT; }
+    int Variant() const override { return m_Illustrative ? VR_VARIANT_ILLUSTRATIVE : VR_VARIANT_MULTI_CTRT; }
+    // renders with MutliCTRTIllustrative.wgsl, the module the reference's IntializePipeline compiles next to
+    // MultiCTRTApp.wgsl but never attaches (MutliCTRTApp.cpp:112-119)
+    void SetIllustrative(bool on) { m_Illustrative = on; }
     const Light* GetLight() const override { return &m_Light1; }
     std::unique_ptr<OpacityTF> p_OpacityTfCT, p_OpacityTfRT;
     std::unique_ptr<ColorTF> p_ColorTfCT, p_ColorTfRT;
 private:
     VolumePtr p_Ct, p_Rt;
+    bool m_Illustrative = false;
     Light m_Light1{vrm::vec4(5.0f, 5.0f, -5.0f, 1.0f), vrm::vec4(0.1f), vrm::vec4(1.0f)};
 };
 

@@ -301,6 +301,12 @@ int vrh_app_start(void* a, int variant, void* v0, void* v1, void* v2, int tf_res
         case VR_VARIANT_VOLUME_MASK: scene = std::make_unique<VolumeMaskApp>(vol(v0), vol(v1), vol(v2)); break;
         case VR_VARIANT_THREE_FILES: scene = std::make_unique<ThreeFilesApp>(vol(v0), vol(v1), vol(v2)); break;
         case VR_VARIANT_MULTI_CTRT: scene = std::make_unique<MultiCTRTApp>(vol(v0), vol(v1)); break;
+        case VR_VARIANT_ILLUSTRATIVE: {
+            auto m = std::make_unique<MultiCTRTApp>(vol(v0), vol(v1));
+            m->SetIllustrative(true);
+            scene = std::move(m);
+            break;
+        }
         case VR_VARIANT_TF_CALIB: scene = std::make_unique<TFCalibrationApp>(vol(v0), vol(v1), vol(v2)); break;
         default: return VR_ERR_INVALID_ARG;
         }

@@ -124,6 +124,7 @@ void variant_needs(int variant, int* nvol, int* ntf)
     case VR_VARIANT_VOLUME_MASK: *nvol = 3; *ntf = 2; break;
     case VR_VARIANT_THREE_FILES: *nvol = 2; *ntf = 2; break;  // the mask (slot 2) is bound but never sampled
     case VR_VARIANT_MULTI_CTRT: *nvol = 2; *ntf = 2; break;
+    case VR_VARIANT_ILLUSTRATIVE: *nvol = 2; *ntf = 2; break;
     default: *nvol = 2; *ntf = 1; break;  // TF_CALIB
     }
 }
@@ -294,6 +295,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         P.light_pos[i] = c->u.light_pos[i];
         P.light_amb[i] = c->u.light_ambient[i];
         P.light_dif[i] = c->u.light_diffuse[i];
+        P.camera_pos[i] = c->u.camera_pos[i];
     }
     for (int i = 0; i < VR_MAX_VOLUMES; ++i) P.vol[i] = c->vol[i];
     for (int i = 0; i < VR_MAX_TFS; ++i) P.tf[i] = c->tf[i];
@@ -323,6 +325,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const double rays_per_lane = (double)px / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
         fl = rays_per_lane >= 4.5 ? 6 : (rays_per_lane >= 2.0 ? 11 : 10);
     }
+    // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
+    if (variant == VR_VARIANT_ILLUSTRATIVE && (fl == 7 || fl == 8 || fl == 10 || fl == 11)) fl = 6;
     c->last_flavour = fl;
     bool can_skip = skip_variant && fl != 1 && fl != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
@@ -462,6 +466,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, P); break;
         case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, P); break;
         case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_ILLUSTRATIVE: launch_variant<V_ILLUSTRATIVE>(off32, leap_mode, grid, block, s, P); break;
         default: launch_variant<V_TF_CALIB>(off32, leap_mode, grid, block, s, P); break;
         }
         VR_HIP(c, hipGetLastError());

@@ -38,6 +38,7 @@ struct MarchParams {
     float bmin[3], bmax[3];  // IsInSampleCoords bounds: 0.0f + clip?.x, 1.0f - clip?.y
     int toggle_varstep, toggle_jitter;
     float light_pos[3], light_amb[3], light_dif[3];
+    float camera_pos[3];     // cameraPosition uniform (illustrative shader only)
     DevVolume vol[3];
     DevTF tf[2];
     // work decomposition: the launch walks the 64x64 tiles t = rank + n*world, n = 0..n_tiles-1

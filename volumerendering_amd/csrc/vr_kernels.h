@@ -22,7 +22,8 @@
 
 namespace vr {
 
-enum Variant : int { V_BASIC = 0, V_LIGHT = 1, V_VOLUME_MASK = 2, V_THREE_FILES = 3, V_MULTI_CTRT = 4, V_TF_CALIB = 5 };
+enum Variant : int { V_BASIC = 0, V_LIGHT = 1, V_VOLUME_MASK = 2, V_THREE_FILES = 3, V_MULTI_CTRT = 4, V_TF_CALIB = 5,
+                     V_ILLUSTRATIVE = 6 };
 
 struct f3 {
     float x, y, z;
@@ -110,6 +111,73 @@ __device__ inline float jitter(float x, float y)
     float s = (float)sin_d((double)d);
     float v = s * 43758.5453f;
     return v - floorf(v);
+}
+
+// WGSL pow(x, y) = exp2(y * log2(x)) through f64 with a fixed operation sequence (oracle: vro_pow, same sequence):
+// log2 by exponent split + atanh series, exp2 by rounding split + Taylor series.  Only the illustrative shader uses it.
+__device__ inline double log2_d(double x)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)b);
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e = e + 1;
+    }
+    double s = (m - 1.0) / (m + 1.0);
+    double s2 = s * s;
+    double t = s2 * (1.0 / 23.0);
+    t = s2 * (t + (1.0 / 21.0));
+    t = s2 * (t + (1.0 / 19.0));
+    t = s2 * (t + (1.0 / 17.0));
+    t = s2 * (t + (1.0 / 15.0));
+    t = s2 * (t + (1.0 / 13.0));
+    t = s2 * (t + (1.0 / 11.0));
+    t = s2 * (t + (1.0 / 9.0));
+    t = s2 * (t + (1.0 / 7.0));
+    t = s2 * (t + (1.0 / 5.0));
+    t = s2 * (t + (1.0 / 3.0));
+    double ln = (2.0 * s) * (t + 1.0);
+    return (double)e + ln * 1.4426950408889634;
+}
+__device__ inline double exp2_d(double t)
+{
+    double n = rint(t);
+    double z = (t - n) * 0.6931471805599453;
+    double r = z * (1.0 / 87178291200.0);
+    r = z * (r + (1.0 / 6227020800.0));
+    r = z * (r + (1.0 / 479001600.0));
+    r = z * (r + (1.0 / 39916800.0));
+    r = z * (r + (1.0 / 3628800.0));
+    r = z * (r + (1.0 / 362880.0));
+    r = z * (r + (1.0 / 40320.0));
+    r = z * (r + (1.0 / 5040.0));
+    r = z * (r + (1.0 / 720.0));
+    r = z * (r + (1.0 / 120.0));
+    r = z * (r + (1.0 / 24.0));
+    r = z * (r + (1.0 / 6.0));
+    r = z * (r + 0.5);
+    r = z * (r + 1.0);
+    r = r + 1.0;
+    int k = (int)n;
+    if (k < -1022) return 0.0;
+    return r * __longlong_as_double((long long)((unsigned long long)(k + 1023) << 52));
+}
+__device__ inline float pow_rep(float x, float y)
+{
+    double lx;
+    if (x != x || x < 0.0f) lx = __longlong_as_double(0x7ff8000000000000LL);
+    else if (x == 0.0f) lx = -__longlong_as_double(0x7ff0000000000000LL);
+    else if (x == __int_as_float(0x7f800000)) lx = __longlong_as_double(0x7ff0000000000000LL);
+    else lx = log2_d((double)x);
+    double t = (double)y * lx;
+    double r;
+    if (t != t) r = __longlong_as_double(0x7ff8000000000000LL);
+    else if (t >= 1024.0) r = __longlong_as_double(0x7ff0000000000000LL);
+    else if (t <= -1100.0) r = 0.0;
+    else r = exp2_d(t);
+    return (float)r;
 }
 
 // ------------------------------------------------------------------------------------------------ sampling
@@ -426,7 +494,7 @@ __device__ __forceinline__ void blend(f3 rgb, float a, float4& dst)  // FrontToB
 template <int V>
 __device__ __forceinline__ bool can_blend(float a)  // the shader's opacity cut-off
 {
-    if constexpr (V == V_BASIC || V == V_MULTI_CTRT || V == V_TF_CALIB)
+    if constexpr (V == V_BASIC || V == V_MULTI_CTRT || V == V_TF_CALIB || V == V_ILLUSTRATIVE)
         return a <= 0.95f;
     else
         return a < 1.0f;
@@ -438,8 +506,9 @@ struct Src {
     f3 rgb;
     float a;
 };
+// (start = the ray's first position and dst_a = the opacity accumulated so far are read by the illustrative shader only)
 template <int V, bool OFF32>
-__device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w)
+__device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 start = f3{0.0f, 0.0f, 0.0f}, float dst_a = 0.0f)
 {
     Src o;
     if constexpr (V == V_BASIC) {
@@ -493,6 +562,29 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w)
                      mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 3.5f, 0.5f);
         o.rgb = mk3(col.x * s.x, col.y * s.y, col.z * s.z);
         o.a = tct.opacity * length3(g);
+    } else if constexpr (V == V_ILLUSTRATIVE) {  // MutliCTRTIllustrative.wgsl:271-310
+        float4 ct = tex3_rgba<OFF32>(P.vol[0], p);
+        float rt = tex3_a<OFF32>(P.vol[1], p);
+        TfSample tct = tf_lookup(P.tf[0], ct.w);
+        TfSample trt = tf_lookup(P.tf[1], rt);
+        float om = 1.0f - trt.opacity;
+        f3 col = mk3(tct.rgb.x * om + trt.rgb.x * trt.opacity, tct.rgb.y * om + trt.rgb.y * trt.opacity,
+                     tct.rgb.z * om + trt.rgb.z * trt.opacity);
+        f3 g = mk3(ct.x, ct.y, ct.z);
+        f3 N = normalize3(g);
+        f3 s3 = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
+                      mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 3.5f, 0.5f);
+        o.rgb = mk3(col.x * s3.x, col.y * s3.y, col.z * s3.z);
+        // IllustrativeContextPreservingOpacity :158-186 (distance in texture space)
+        f3 L = normalize3(mk3(0.0f - w.x, -5.0f - w.y, 0.0f - w.z));
+        f3 Vv = normalize3(mk3(P.camera_pos[0] - w.x, P.camera_pos[1] - w.y, P.camera_pos[2] - w.z));
+        f3 H = normalize3(mk3(Vv.x + L.x, Vv.y + L.y, Vv.z + L.z));
+        float s = (0.5f + 2.5f * length3(mk3(L.x * g.x, L.y * g.y, L.z * g.z))) +
+                  1.0f * pow_rep(length3(mk3(H.x * g.x, H.y * g.y, H.z * g.z)), 1.0f);
+        float dist = length3(mk3(p.x - start.x, p.y - start.y, p.z - start.z));
+        if (dist > 1.0f) dist = 1.0f;
+        float inner = pow_rep(((5.0f * s) * (1.0f - dist)) * (1.0f - dst_a), 0.8f);
+        o.a = tct.opacity * pow_rep(length3(g), inner);
     } else {  // V_TF_CALIB
         float density = tex3_a<OFF32>(P.vol[0], p);
         float4 mask = tex3_nearest<OFF32>(P.vol[1], p);
@@ -507,9 +599,9 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w)
     return o;
 }
 template <int V, bool OFF32>
-__device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst)
+__device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst, f3 start)
 {
-    const Src s = sample_src<V, OFF32>(P, p, w);
+    const Src s = sample_src<V, OFF32>(P, p, w, start, dst.w);
     blend(s.rgb, s.a, dst);
 }
 
@@ -725,7 +817,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                     p = mk3(p.x + (dir.x * step_size) * j, p.y + (dir.y * step_size) * j, p.z + (dir.z * step_size) * j);
                 }
                 f3 step = mk3(dir.x * step_size, dir.y * step_size, dir.z * step_size);
-                if constexpr (V == V_MULTI_CTRT) {  // CalculateWorldStep after the override
+                if constexpr (V == V_MULTI_CTRT || V == V_ILLUSTRATIVE) {  // CalculateWorldStep after the override
                     wstep = mk3(dir.x * (step_size * 1.0f), dir.y * (step_size * 1.0f), dir.z * (step_size * 0.7f));
                     wstep.z = wstep.z * (-1.0f);
                 }
@@ -884,7 +976,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                                     blend(t.rgb, t.opacity, dst);
                                 }
                             } else {
-                                sample_and_blend<V, OFF32>(P, p, w, dst);
+                                sample_and_blend<V, OFF32>(P, p, w, dst, ray.start);
                             }
                             ++fetched;
                             ++blends;
