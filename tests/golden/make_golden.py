@@ -30,6 +30,9 @@ def cases():
     out.append(("basic_jitter", 0, dict(base, toggles=(0, 1, 0, 0)), False))
     for m in (1, 2, 3, 4):
         out.append((f"mode{m}", 1, dict(base, fragment_mode=m), False))
+    # the illustrative shader, rays kept shorter than 1 in texture space (beyond that its pow(0, 0) puts NaNs -- whose
+    # payload bits are platform specific -- into the frame; tests/test_parity_gpu.py covers those NaN-aware)
+    out.append(("illustrative", 6, dict(base, steps_count=12, yaw=0.9), False))
     return out
 
 
