@@ -29,6 +29,7 @@ def main():
         ctx.set_kernel_flavour(fl)
         for world in (1, 2, 4, 8):
             worst = 0.0
+            per_rank = []
             for rank in range(world):
                 for _ in range(3):
                     ctx.render_tiles(variant, rank, world)
@@ -37,7 +38,9 @@ def main():
                     ctx.render_tiles(variant, rank, world)
                 t = float(np.median(ctx.kernel_times()))
                 worst = max(worst, t)
-            print(f"flavour {fl} world {world}: slowest rank's kernel {worst:.4f} ms", flush=True)
+                per_rank.append(t)
+            print(f"flavour {fl} world {world}: slowest rank's kernel {worst:.4f} ms   (ranks: "
+                  + " ".join(f"{t:.3f}" for t in per_rank) + ")", flush=True)
 
 
 if __name__ == "__main__":

@@ -893,8 +893,9 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                         // additions back to back (nothing else per step), then look their brick up again.  The rays
                         // of a packet stay at one step index, so their samples keep sharing cache lines.
                         int m = 0;
-                        if (D >= 2) m = min((int)fminf(((float)D - 1.0625f) * leap_c, 64.0f), lim - i - 1);
-                        if (__ballot(m < 4) == 0) {
+                        const bool far = __ballot(D < 2) == 0;  // (one vote decides for a packet that is sampling)
+                        if (far) m = min((int)fminf(((float)D - 1.0625f) * leap_c, 64.0f), lim - i - 1);
+                        if (far && __ballot(m < 4) == 0) {
                             int mw = 4;
                             if (__ballot(m < 8) == 0) {
                                 mw = 8;
@@ -924,10 +925,10 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                     int adv = 1;  // steps this iteration advances by
                     if (inb) {
                         if (!SKIP || D == 0) {
-                            if (P.prio_mode == 1) {
+                            if (P.prio_mode == 1 && (__builtin_amdgcn_readfirstlane(i) & 7) == 0) {
                                 // longest-remaining-path-first: the frame is done when its longest ray is, so wavefronts
                                 // whose rays still have far to go get the issue slots first (4 levels, by quarters of
-                                // stepsCount; speed only)
+                                // stepsCount; re-evaluated every 8th step; speed only)
                                 const int r = lim - i;
                                 if (__ballot(r > prio_q3) != 0) __builtin_amdgcn_s_setprio(3);
                                 else if (__ballot(r > prio_q2) != 0) __builtin_amdgcn_s_setprio(2);
