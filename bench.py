@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flavour", type=int, default=0)
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="frames in flight on one GPU: 2 = alternate two streams and two frame buffers, so that the next "
+                         "frame fills the machine while the longest rays of the previous one drain (N = 1 only)")
     ap.add_argument("--exp-mode", type=int, default=0, help="experiment: fragmentMode 1-4 (ray set-up only)")
     ap.add_argument("--exp-steps", type=int, default=-1, help="experiment: override stepsCount")
     args = ap.parse_args()
@@ -175,6 +178,11 @@ def main():
     tpr_max = ctx.tile_count(0, world)
     tile_floats = capi.TILE * capi.TILE * 4
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    in_flight = args.in_flight if world == 1 else 1
+    if in_flight == 2:  # a second frame buffer and stream; frames alternate between the two
+        frames2 = [frame, torch.zeros_like(frame)]
+        streams2 = [torch.cuda.current_stream(), torch.cuda.Stream()]
+        streams2[1].wait_stream(streams2[0])
     if world > 1:
         # two tile buffers: the gather of frame k overlaps the render of frame k+1 (one frame of latency, as any
         # pipelined renderer has); every frame's gather and un-permute completes inside the timed region
@@ -185,6 +193,10 @@ def main():
 
     def run_frames(n_frames):
         if world == 1:
+            if in_flight == 2:
+                for k in range(n_frames):
+                    ctx.render_async(variant, frames2[k & 1].data_ptr(), streams2[k & 1].cuda_stream)
+                return
             for _ in range(n_frames):
                 ctx.render_async(variant, frame.data_ptr(), stream)
             return
@@ -272,7 +284,7 @@ def main():
         "config": {
             "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, "
                         f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
-            "partition": "single GPU" if world == 1 else
+            "partition": ("single GPU, 2 frames in flight" if in_flight == 2 else "single GPU") if world == 1 else
                          f"64x64 image tiles interleaved over {world} GPUs + RCCL gather (pipelined one frame deep)",
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
             "covered_pixels": covered, "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
@@ -282,6 +294,10 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
             "kernel": KERNEL_OF_FLAVOUR.get(ran, "march_kernel"), "kernel_ms": round(kernel_ms, 4), "bytes_per_sample": bs,
             "algorithmic_bytes_per_launch": alg_bytes,
+            # with two frames in flight two launches overlap: each one's own duration (kernel_ms, what rocprofv3 reports
+            # too) is longer than the time the GPU spends per frame; the rate of the overlapped pair is given as well
+            "launches_in_flight": in_flight,
+            "achieved_per_frame_time": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

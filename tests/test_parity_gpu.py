@@ -447,3 +447,60 @@ def test_illustrative_shader_reads_alpha_and_camera(ctx):
     a, _, _ = vt.gpu_render(ctx, capi.ILLUSTRATIVE, hr.make_uniforms(W, H, steps_count=count, step_size=step), vols, tfs)
     b, _, _ = vt.gpu_render(ctx, capi.MULTI_CTRT, hr.make_uniforms(W, H, steps_count=count, step_size=step), vols, tfs)
     assert not np.array_equal(a, b)
+
+
+def test_two_frames_in_flight_on_two_streams(ctx):
+    """vr_render_async on two streams into two device buffers, alternating (what bench.py does on one GPU so that the
+    next frame fills the machine while the previous one's longest rays drain): every frame equals the synchronous
+    render bit for bit, and the counts read afterwards are those of the last frame."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")  # the runtime libvr_hip.so itself is linked against
+
+    def ok(rc):
+        assert rc == 0, rc
+
+    W, H = 256, 160
+    nbytes = W * H * 16
+    vols, tfs = vt.scene(capi.LIGHT, n=32)
+    step, count = hr.stepping_params(32, 32, 32)
+    ctx.resize(W, H)
+    bufs, streams = [C.c_void_p(), C.c_void_p()], [C.c_void_p(), C.c_void_p()]
+    for i in range(2):
+        ok(hip.hipMalloc(C.byref(bufs[i]), C.c_size_t(nbytes)))
+        ok(hip.hipStreamCreate(C.byref(streams[i])))
+
+    def fetch(i):
+        out = np.empty((H, W, 4), dtype=np.float32)
+        ok(hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), bufs[i], C.c_size_t(nbytes), 2))  # hipMemcpyDeviceToHost
+        return out
+
+    try:
+        u1 = hr.make_uniforms(W, H, steps_count=count, step_size=step)
+        ref1, _, n1 = vt.gpu_render(ctx, capi.LIGHT, u1, vols, tfs)
+        u2 = hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=2.0, pitch=-0.3)
+        ctx.set_uniforms(vt.to_capi_uniforms(u2))
+        ctx.render(capi.LIGHT)
+        ref2, _, n2 = ctx.download()
+        assert n1 != n2
+        for fl in (0, 6, 10):
+            ctx.set_kernel_flavour(fl)
+            for k in range(8):  # same uniforms for a whole burst: they are read when the launch is enqueued
+                ctx.render_async(capi.LIGHT, bufs[k & 1].value, streams[k & 1].value)
+            ok(hip.hipDeviceSynchronize())
+            assert ctx.counters()[0] == n2
+            for i in range(2):
+                assert np.array_equal(vt.bits(fetch(i)), vt.bits(ref2))
+            ctx.set_uniforms(vt.to_capi_uniforms(u1))
+            ctx.render_async(capi.LIGHT, bufs[0].value, streams[0].value)
+            ctx.set_uniforms(vt.to_capi_uniforms(u2))
+            ctx.render_async(capi.LIGHT, bufs[1].value, streams[1].value)
+            ok(hip.hipDeviceSynchronize())
+            assert np.array_equal(vt.bits(fetch(0)), vt.bits(ref1))
+            assert np.array_equal(vt.bits(fetch(1)), vt.bits(ref2))
+            assert ctx.counters()[0] == n2
+    finally:
+        ctx.set_kernel_flavour(0)
+        ctx.resize(96, 80)
+        for i in range(2):
+            hip.hipStreamDestroy(streams[i])
+            hip.hipFree(bufs[i])

@@ -60,8 +60,12 @@ struct vr_ctx {
     int last_tiles = 0;         // tiles rendered by the last vr_render_tiles
     uint32_t* d_present = nullptr;
     unsigned long long* d_counters = nullptr;  // [3] composited, covered, fetched
-    unsigned long long* d_block_counts = nullptr;  // per-block partial sums of the last launch
-    size_t block_counts_cap = 0;               // in blocks
+    // per-workgroup records (store_block_counts), two buffers used alternately so that two frames can be in flight on
+    // two streams (the second starts filling the machine while the first one's long rays drain)
+    unsigned long long* d_block_counts[2] = {nullptr, nullptr};
+    size_t block_counts_cap[2] = {0, 0};       // in blocks
+    unsigned launch_seq = 0;
+    int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
     int cnt_blocks = 0;
     hipStream_t cnt_stream = nullptr;
@@ -366,6 +370,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const int nb = P.bnx * P.bny * P.bnz;
         if (c->dist_records != (const void*)P.bricks || c->dist_epoch != c->brick_epoch || c->dist_z != P.tf_zero_prefix ||
             c->dist_res != c->tf[0].res_o || c->dist_rgb != P.use_rgb || !c->brick_dist) {
+            // (rare: an input changed.  Frames may be in flight on other streams and read the field: drain them first,
+            // and finish the rebuild before any other stream's launch can follow)
+            VR_HIP(c, hipDeviceSynchronize());
             if ((size_t)nb > c->dist_cap) {
                 if (c->brick_dist) (void)hipFree(c->brick_dist);
                 c->brick_dist = nullptr;
@@ -380,6 +387,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 hipLaunchKernelGGL(brick_dist_pass_kernel, g, b, 0, s, c->brick_dist, P.bnx, P.bny, P.bnz, k);
             hipLaunchKernelGGL(brick_dist_cap_kernel, g, b, 0, s, c->brick_dist, nb);
             VR_HIP(c, hipGetLastError());
+            VR_HIP(c, hipStreamSynchronize(s));
             c->dist_records = (const void*)P.bricks;
             c->dist_epoch = c->brick_epoch;
             c->dist_z = P.tf_zero_prefix;
@@ -415,15 +423,17 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const int wpb = wtb ? 4 : c->waves_per_block;
         dim3 block((unsigned)(dp ? 256 : 64 * wpb));
         dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 64 : 32) : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel
-        if (grid.x > c->block_counts_cap) {
-            if (c->d_block_counts) (void)hipFree(c->d_block_counts);
-            c->d_block_counts = nullptr;
-            c->block_counts_cap = 0;
-            VR_HIP(c, hipMalloc(&c->d_block_counts, (size_t)grid.x * kBlockRecord * sizeof(unsigned long long)));
-            VR_HIP(c, hipMemsetAsync(c->d_block_counts, 0, (size_t)grid.x * kBlockRecord * sizeof(unsigned long long), s));
-            c->block_counts_cap = grid.x;
+        const int cb = (int)(c->launch_seq++ & 1u);
+        if (grid.x > c->block_counts_cap[cb]) {
+            if (c->d_block_counts[cb]) (void)hipFree(c->d_block_counts[cb]);
+            c->d_block_counts[cb] = nullptr;
+            c->block_counts_cap[cb] = 0;
+            VR_HIP(c, hipMalloc(&c->d_block_counts[cb], (size_t)grid.x * kBlockRecord * sizeof(unsigned long long)));
+            VR_HIP(c, hipMemsetAsync(c->d_block_counts[cb], 0, (size_t)grid.x * kBlockRecord * sizeof(unsigned long long), s));
+            c->block_counts_cap[cb] = grid.x;
         }
-        P.block_counts = c->d_block_counts;
+        P.block_counts = c->d_block_counts[cb];
+        c->cnt_buf = cb;
         const int slot = (int)(c->ring.head % kRing);
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
         VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
@@ -495,7 +505,7 @@ int fetch_counters(vr_ctx* c)
     if (!c->cnt_pending) return VR_OK;
     VR_HIP(c, hipSetDevice(c->device));
     if (c->cnt_blocks > 0) {
-        hipLaunchKernelGGL(sum_block_counts_kernel, dim3(1), dim3(256), 0, c->cnt_stream, c->d_block_counts, c->cnt_blocks,
+        hipLaunchKernelGGL(sum_block_counts_kernel, dim3(1), dim3(256), 0, c->cnt_stream, c->d_block_counts[c->cnt_buf], c->cnt_blocks,
                            c->d_counters);
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipMemcpyAsync(c->h_counters, c->d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -735,7 +745,8 @@ void vr_destroy(vr_ctx* c)
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_present) (void)hipFree(c->d_present);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->d_block_counts) (void)hipFree(c->d_block_counts);
+    for (auto* b : c->d_block_counts)
+        if (b) (void)hipFree(b);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (int i = 0; i < kRing; ++i) {
         if (c->ring.k0[i]) (void)hipEventDestroy(c->ring.k0[i]);
@@ -1025,7 +1036,8 @@ int vr_last_block_trace(vr_ctx* c, uint64_t* out, int capacity)
     if (c->cnt_stream) VR_HIP(c, hipStreamSynchronize(c->cnt_stream));
     const int n = c->cnt_blocks < capacity ? c->cnt_blocks : capacity;
     if (n > 0)
-        VR_HIP(c, hipMemcpy(out, c->d_block_counts, (size_t)n * kBlockRecord * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        VR_HIP(c, hipMemcpy(out, c->d_block_counts[c->cnt_buf], (size_t)n * kBlockRecord * sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost));
     return c->cnt_blocks;
 }
 
