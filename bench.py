@@ -178,54 +178,53 @@ def main():
     tpr_max = ctx.tile_count(0, world)
     tile_floats = capi.TILE * capi.TILE * 4
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    in_flight = args.in_flight if world == 1 else 1
-    if in_flight == 2:  # a second frame buffer and stream; frames alternate between the two
-        frames2 = [frame, torch.zeros_like(frame)]
-        streams2 = [torch.cuda.current_stream(), torch.cuda.Stream()]
-        streams2[1].wait_stream(streams2[0])
+    in_flight = args.in_flight
+    # two streams and two sets of buffers, used alternately: frame k+1 starts while frame k's longest rays drain
+    # (and, with N > 1, while frame k's tiles travel); --in-flight 1 keeps everything on one stream
+    streams2 = [torch.cuda.current_stream(), torch.cuda.Stream() if in_flight == 2 else torch.cuda.current_stream()]
+    streams2[1].wait_stream(streams2[0])
+    frames2 = [frame, torch.zeros_like(frame) if in_flight == 2 else frame]
     if world > 1:
-        # two tile buffers: the gather of frame k overlaps the render of frame k+1 (one frame of latency, as any
-        # pipelined renderer has); every frame's gather and un-permute completes inside the timed region
+        # every frame's gather and un-permute completes inside the timed region
         my_tiles = [torch.zeros((tpr_max * tile_floats,), dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered = [torch.zeros((world, tpr_max * tile_floats), dtype=torch.float32, device="cuda") for _ in range(2)] \
             if rank == 0 else [None, None]
         gather_list = [[g[r] for r in range(world)] for g in gathered] if rank == 0 else [None, None]
 
+    def finish(b, work):
+        """Frame in buffer set b: wait for its gather (orders the current stream behind it, no host block), un-permute."""
+        if work is not None:
+            work.wait()
+        if rank == 0:
+            ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames2[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
+
     def run_frames(n_frames):
         if world == 1:
-            if in_flight == 2:
-                for k in range(n_frames):
-                    ctx.render_async(variant, frames2[k & 1].data_ptr(), streams2[k & 1].cuda_stream)
-                return
-            for _ in range(n_frames):
-                ctx.render_async(variant, frame.data_ptr(), stream)
+            for k in range(n_frames):
+                ctx.render_async(variant, frames2[k & 1].data_ptr(), streams2[k & 1].cuda_stream)
             return
-        pending = None  # (work handle, buffer index) of the previous frame's gather
+        pending = [None, None]  # per buffer set: (work handle,) of the frame that last used it
         for k in range(n_frames):
             b = k & 1
-            ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), stream)
-            if backend == "nccl":
-                # RCCL over xGMI: every peer sends straight to the root (7 links in parallel, not a ring)
-                work = dist.gather(my_tiles[b], gather_list[b], dst=0, async_op=True)
-            else:  # rehearsal only: through host memory, synchronous
-                host_list = [torch.empty(my_tiles[b].numel()) for _ in range(world)] if rank == 0 else None
-                dist.gather(my_tiles[b].cpu(), host_list, dst=0)
-                if rank == 0:
-                    gathered[b].copy_(torch.stack(host_list))
-                work = None
-            if pending is not None:
-                pw, pb = pending
-                if pw is not None:
-                    pw.wait()  # orders the current stream after that gather (no host block)
-                if rank == 0:
-                    ctx.unpack_tiles_async(gathered[pb].data_ptr(), world, frame.data_ptr(), stream)
-            pending = (work, b)
-        if pending is not None:
-            pw, pb = pending
-            if pw is not None:
-                pw.wait()
-            if rank == 0:
-                ctx.unpack_tiles_async(gathered[pb].data_ptr(), world, frame.data_ptr(), stream)
+            with torch.cuda.stream(streams2[b]):
+                if pending[b] is not None:  # frame k-2 used these buffers: its tiles must have left before they are reused
+                    finish(b, pending[b][0])
+                ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), streams2[b].cuda_stream)
+                if backend == "nccl":
+                    # RCCL over xGMI: every peer sends straight to the root (7 links in parallel, not a ring); the
+                    # collective is ordered behind this stream's render and runs on RCCL's own stream
+                    work = dist.gather(my_tiles[b], gather_list[b], dst=0, async_op=True)
+                else:  # rehearsal only: through host memory, synchronous
+                    host_list = [torch.empty(my_tiles[b].numel()) for _ in range(world)] if rank == 0 else None
+                    dist.gather(my_tiles[b].cpu(), host_list, dst=0)
+                    if rank == 0:
+                        gathered[b].copy_(torch.stack(host_list))
+                    work = None
+                pending[b] = (work,)
+        for b in ((n_frames & 1), ((n_frames + 1) & 1)):  # the older of the two outstanding frames first
+            if pending[b] is not None:
+                with torch.cuda.stream(streams2[b]):
+                    finish(b, pending[b][0])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -284,8 +283,9 @@ def main():
         "config": {
             "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, "
                         f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
-            "partition": ("single GPU, 2 frames in flight" if in_flight == 2 else "single GPU") if world == 1 else
-                         f"64x64 image tiles interleaved over {world} GPUs + RCCL gather (pipelined one frame deep)",
+            "partition": ("single GPU" if world == 1 else
+                          f"64x64 image tiles interleaved over {world} GPUs + RCCL gather") +
+                         (", 2 frames in flight" if in_flight == 2 else ", one frame at a time"),
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
             "covered_pixels": covered, "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
         },
@@ -310,7 +310,7 @@ def main():
         ctx.render_async(variant, 0, stream)
         torch.cuda.synchronize()
         ref, _, _ = ctx.download()
-        same = bool(np.array_equal(ref.view(np.uint32), frame.cpu().numpy().view(np.uint32)))
+        same = all(bool(np.array_equal(ref.view(np.uint32), f.cpu().numpy().view(np.uint32))) for f in frames2)
         out["config"]["frame_equals_single_rank_render"] = same
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Experiment: march-kernel time of ONE rank's share of the frame (tile t owned by rank t mod N) on one GPU, for
-several kernel flavours -- what each GPU of an N-GPU run has to do, without the gather.
+"""Experiment: what each GPU of an N-GPU run has to do, measured on ONE GPU -- the march kernel of one rank's share of
+the frame (tile t owned by rank t mod N), without the gather, for several kernel flavours:
+  * kernel ms of the slowest rank, one launch at a time (HIP events), and
+  * ms per frame with two launches in flight on two streams, as bench.py drives them (wall clock, rank 0's share).
 
     python tools_exp_tiles.py [--workload C3] [--tf default] [--flavours 0,6]"""
 import argparse
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -19,17 +22,19 @@ def main():
     ap.add_argument("--tf", default="default")
     ap.add_argument("--flavours", default="0,6")
     a = ap.parse_args()
+    import torch  # first: torch's HIP runtime has to initialise before libvr_hip.so's
+    torch.cuda.init()
     import bench
     from volumerendering_amd import capi, host, synth
     n, W, H, vname = bench.WORKLOADS[a.workload]
     app = host.Application(W, H, 0)
     variant, vols = bench.build_scene(app, host, synth, capi, a.workload, a.tf)
     ctx = app.context()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     for fl in [int(x) for x in a.flavours.split(",")]:
         ctx.set_kernel_flavour(fl)
         for world in (1, 2, 4, 8):
-            worst = 0.0
-            per_rank = []
+            worst, per_rank = 0.0, []
             for rank in range(world):
                 for _ in range(3):
                     ctx.render_tiles(variant, rank, world)
@@ -39,8 +44,21 @@ def main():
                 t = float(np.median(ctx.kernel_times()))
                 worst = max(worst, t)
                 per_rank.append(t)
-            print(f"flavour {fl} world {world}: slowest rank's kernel {worst:.4f} ms   (ranks: "
-                  + " ".join(f"{t:.3f}" for t in per_rank) + ")", flush=True)
+            ran = ctx.last_kernel_flavour()
+            nfl = ctx.tile_count(0, world) * capi.TILE * capi.TILE * 4
+            bufs = [torch.zeros(nfl, dtype=torch.float32, device="cuda") for _ in range(2)]
+
+            def burst(k):
+                for i in range(k):
+                    ctx.render_tiles_async(variant, 0, world, bufs[i & 1].data_ptr(), streams[i & 1].cuda_stream)
+                torch.cuda.synchronize()
+
+            burst(6)
+            t0 = time.perf_counter()
+            burst(40)
+            two = (time.perf_counter() - t0) / 40 * 1e3
+            print(f"flavour {fl} (ran {ran}) world {world}: slowest rank's kernel {worst:.4f} ms, rank 0 with two in flight "
+                  f"{two:.4f} ms/frame   (ranks: " + " ".join(f"{t:.3f}" for t in per_rank) + ")", flush=True)
 
 
 if __name__ == "__main__":

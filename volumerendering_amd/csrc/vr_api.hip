@@ -324,10 +324,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // Default: pick the lanes per ray from the size of the launch.  With many rays per hardware lane the machine
         // is throughput-bound and one lane per ray does the least work; with few (a small frame, or one GPU's share
         // of the tiles) the frame waits for its longest rays, whose chains of dependent steps the depth-parallel
-        // kernel cuts to a half or a quarter (vr_dp.h).  Thresholds measured on C3 at 1 / 2 / 4 / 8 ranks.
+        // kernel cuts to a half or a quarter (vr_dp.h).  Thresholds measured on C3 at 1 / 2 / 4 / 8 ranks (two launches in
+        // flight, tools_exp_tiles.py).
         const long long px = (long long)tile_count(c, rank, world) * kTile * kTile;
         const double rays_per_lane = (double)px / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
-        fl = rays_per_lane >= 4.5 ? 6 : (rays_per_lane >= 2.0 ? 11 : 10);
+        fl = rays_per_lane >= 4.5 ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
     }
     // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
     if (variant == VR_VARIANT_ILLUSTRATIVE && (fl == 7 || fl == 8 || fl == 10 || fl == 11)) fl = 6;
