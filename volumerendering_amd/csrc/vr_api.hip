@@ -253,10 +253,12 @@ void launch_dp(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
 #undef VR_LAUNCH_DP
 }
 
+// finite and of moderate size: products of a colour, a light term and a shading factor stay finite, so "x * 0 == 0"
+// holds for everything a provably-zero opacity is multiplied with
 bool all_finite(const float* v, int n)
 {
     for (int i = 0; i < n; ++i)
-        if (!(v[i] - v[i] == 0.0f)) return false;
+        if (!(v[i] - v[i] == 0.0f) || !(v[i] <= 1.0e15f && v[i] >= -1.0e15f)) return false;
     return true;
 }
 
