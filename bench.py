@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flavour", type=int, default=0)
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="frames in flight on one GPU: 2 = alternate two streams and two frame buffers, so that the next "
                          "frame fills the machine while the longest rays of the previous one drain (N = 1 only)")
     ap.add_argument("--exp-mode", type=int, default=0, help="experiment: fragmentMode 1-4 (ray set-up only)")
@@ -181,9 +181,13 @@ def main():
     in_flight = args.in_flight
     # two streams and two sets of buffers, used alternately: frame k+1 starts while frame k's longest rays drain
     # (and, with N > 1, while frame k's tiles travel); --in-flight 1 keeps everything on one stream
-    streams2 = [torch.cuda.current_stream(), torch.cuda.Stream() if in_flight == 2 else torch.cuda.current_stream()]
-    streams2[1].wait_stream(streams2[0])
-    frames2 = [frame, torch.zeros_like(frame) if in_flight == 2 else frame]
+    nbuf = in_flight if world == 1 else min(in_flight, 2)
+    streams2 = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nbuf - 1)]
+    for st in streams2[1:]:
+        st.wait_stream(streams2[0])
+    frames2 = [frame] + [torch.zeros_like(frame) for _ in range(nbuf - 1)]
+    if nbuf == 1:
+        streams2, frames2 = streams2 * 2, frames2 * 2
     if world > 1:
         # every frame's gather and un-permute completes inside the timed region
         my_tiles = [torch.zeros((tpr_max * tile_floats,), dtype=torch.float32, device="cuda") for _ in range(2)]
@@ -201,7 +205,7 @@ def main():
     def run_frames(n_frames):
         if world == 1:
             for k in range(n_frames):
-                ctx.render_async(variant, frames2[k & 1].data_ptr(), streams2[k & 1].cuda_stream)
+                ctx.render_async(variant, frames2[k % nbuf].data_ptr(), streams2[k % nbuf].cuda_stream)
             return
         pending = [None, None]  # per buffer set: (work handle,) of the frame that last used it
         for k in range(n_frames):
@@ -285,7 +289,7 @@ def main():
                         f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
             "partition": ("single GPU" if world == 1 else
                           f"64x64 image tiles interleaved over {world} GPUs + RCCL gather") +
-                         (", 2 frames in flight" if in_flight == 2 else ", one frame at a time"),
+                         (f", {nbuf} frames in flight" if nbuf > 1 else ", one frame at a time"),
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
             "covered_pixels": covered, "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
         },
@@ -296,7 +300,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             # with two frames in flight two launches overlap: each one's own duration (kernel_ms, what rocprofv3 reports
             # too) is longer than the time the GPU spends per frame; the rate of the overlapped pair is given as well
-            "launches_in_flight": in_flight,
+            "launches_in_flight": nbuf,
             "achieved_per_frame_time": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
         },
     }

@@ -178,9 +178,10 @@ int vr_tile_count(const vr_ctx* ctx, int rank, int world);
 /* Asynchronous forms: enqueue on `stream` (a hipStream_t, NULL = the ctx's own stream) and write
  * to DEVICE memory supplied by the caller; nothing is synchronised.  `d_frame` = W*H*4 floats;
  * `d_tiles` as described above.  These are what a multi-rank host (RCCL gather) drives.
- * Up to TWO renders may be in flight at a time, on two different streams and into two different
- * buffers (alternate them): the second frame fills the machine while the first one's longest rays
- * drain.  The caller synchronises its streams before it changes volumes, tables or the size.     */
+ * Up to FOUR renders may be in flight at a time, each on its own stream and into its own buffer (use
+ * them in turn): the next frame fills the machine while the previous one's longest rays drain (two in
+ * flight give 1.45x the frame rate of one on C3, three 1.5x).  The caller synchronises its streams
+ * before it changes volumes, tables or the size.                                                  */
 int vr_render_async(vr_ctx* ctx, int variant, void* d_frame, void* stream);
 int vr_render_tiles_async(vr_ctx* ctx, int variant, int rank, int world, void* d_tiles, void* stream);
 

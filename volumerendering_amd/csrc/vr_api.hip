@@ -31,6 +31,8 @@ struct KernelRing {  // one (start, stop) event pair per render call, reused rou
 
 }  // namespace
 
+constexpr int kInFlight = 4;  // renders that may be in flight at a time (one stream and one output buffer each)
+
 struct vr_ctx {
     int device = 0;
     uint32_t W = 0, H = 0;
@@ -60,10 +62,10 @@ struct vr_ctx {
     int last_tiles = 0;         // tiles rendered by the last vr_render_tiles
     uint32_t* d_present = nullptr;
     unsigned long long* d_counters = nullptr;  // [3] composited, covered, fetched
-    // per-workgroup records (store_block_counts), two buffers used alternately so that two frames can be in flight on
-    // two streams (the second starts filling the machine while the first one's long rays drain)
-    unsigned long long* d_block_counts[2] = {nullptr, nullptr};
-    size_t block_counts_cap[2] = {0, 0};       // in blocks
+    // per-workgroup records (store_block_counts), kInFlight buffers used in turn so that several frames can be in
+    // flight on different streams (the next ones fill the machine while the first one's long rays drain)
+    unsigned long long* d_block_counts[kInFlight] = {};
+    size_t block_counts_cap[kInFlight] = {};   // in blocks
     unsigned launch_seq = 0;
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
@@ -426,7 +428,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const int wpb = wtb ? 4 : c->waves_per_block;
         dim3 block((unsigned)(dp ? 256 : 64 * wpb));
         dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 64 : 32) : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel
-        const int cb = (int)(c->launch_seq++ & 1u);
+        const int cb = (int)(c->launch_seq++ % (unsigned)kInFlight);
         if (grid.x > c->block_counts_cap[cb]) {
             if (c->d_block_counts[cb]) (void)hipFree(c->d_block_counts[cb]);
             c->d_block_counts[cb] = nullptr;
