@@ -1,5 +1,7 @@
 // vr_kernels.h -- hand-written HIP kernels for gfx950 (MI355X / CDNA4): the front-to-back compositing loop
-// of the reference's WGSL fragment shaders, one ray per lane, one 8x8 pixel packet per 64-wide wavefront.
+// of the reference's WGSL fragment shaders, one ray per lane, one 8x8 pixel packet per 64-wide wavefront
+// (march_kernel; vr_dp.h holds the two / four lanes per ray form, vr_wtb.h the LDS wave-tile experiment), plus the
+// auxiliary kernels (brick records and distance field, counters, present, tile unpack, data preparation).
 //
 // What each piece replaces (paths below the reference root):
 //   setup_ray()      rayCoords.wgsl:19-34 + vertex stage BasicVolumeApp.wgsl:44-57 + rasteriser, proxy box
@@ -8,7 +10,7 @@
 //   tf_*()           textureSample(texture_1d, samplerLin, d)
 //   march_kernel<V>  fs_main of BasicVolumeApp.wgsl:113-188, BasicVolLightApp.wgsl:151-237,
 //                    VolumeMaskApp.wgsl:128-217, ThreeFilesApp.wgsl:170-272, MultiCTRTApp.wgsl:163-259,
-//                    TFCalibrationApp.wgsl:114-197
+//                    TFCalibrationApp.wgsl:114-197, MutliCTRTIllustrative.wgsl:227-313
 //   present_kernel   output merge PipelineBuilder.cpp:142-147 over fullscreen.wgsl:33-41 white, BGRA8Unorm
 //
 // Arithmetic contract (DESIGN.md "Normative arithmetic"): IEEE f32, no FMA contraction (-ffp-contract=off),
