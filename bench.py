@@ -279,6 +279,25 @@ def main():
             traffic = None
 
     ran = ctx.last_kernel_flavour()
+    # second denominator: what a plain device-to-device copy reaches on this GPU right now
+    d2d_gbs = None
+    if rank == 0:
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")  # 1 GiB
+            dstb = torch.empty_like(src)
+            dstb.copy_(src)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dstb.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            d2d_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # bytes read + written
+            del src, dstb
+        except Exception:
+            d2d_gbs = None
+
     out = {
         "metric": "Gsamples/s", "value": round(value, 4), "unit": "Gsamples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -300,6 +319,8 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             # with two frames in flight two launches overlap: each one's own duration (kernel_ms, what rocprofv3 reports
             # too) is longer than the time the GPU spends per frame; the rate of the overlapped pair is given as well
+            "d2d_copy_gbs": round(d2d_gbs, 1) if d2d_gbs else None,
+            "frac_of_d2d_copy": round(achieved / d2d_gbs, 4) if (achieved and d2d_gbs) else None,
             "launches_in_flight": nbuf,
             "achieved_per_frame_time": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
         },
