@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
     }
     unsigned D = 0;  // distance-field byte of p: 0 = sample, k >= 1 = identity, and so is everything within k-1 bricks
     if constexpr (SKIP) {
-        D = P.brick_dist[brick_of(P, p)];
+        D = dist_at(P, brick_of(P, p));
         if constexpr (PIPE) asm volatile("" : "+v"(D));
     }
     const int lim = min(n_inside, P.steps_count);  // runs stay inside the provably-in-box prefix
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
             if constexpr (kW) wn = mk3(wn.x + wstep.x, wn.y + wstep.y, wn.z + wstep.z);
         }
         unsigned Dn = 0;
-        if constexpr (SKIP) Dn = P.brick_dist[brick_of(P, pn)];
+        if constexpr (SKIP) Dn = dist_at(P, brick_of(P, pn));
 
         if constexpr (SKIP) {
             // wave-uniform run of identity steps (march_kernel): every slot of every ray that is still marching
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
                 }
                 base += mw;
                 blends += alive ? (unsigned)mw : 0u;
-                D = P.brick_dist[brick_of(P, p)];
+                D = dist_at(P, brick_of(P, p));
                 if constexpr (PIPE) asm volatile("" : "+v"(D));  // no path reaches the loop head with a load pending
                 have = false;
                 continue;

@@ -657,15 +657,32 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
 // bit-identical (rgb is finite: the host checks tables and light).  Interpolated densities can exceed bm by a
 // few ulps, which moves the table index by at most one: hence the +2 (floor + 1 neighbour + 1 margin).
 // bm <= 0 (all-zero / negative cells) only ever addresses opacity[0].  NaN bm fails every comparison -> active.
+template <bool FMED = true>
 __device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
 {
     // brick coordinate of the base cell: clamp(floor(p*n - 0.5), 0, n-1) >> 3.  Scaling by 1/8 is exact and commutes
     // with f32 rounding, and floor(floor(x)/8) == floor(x/8), so this is the same integer as
-    // clamp(floor(p*(n/8) - 1/16), 0, (n-1) >> 3) -- five instructions per axis instead of seven.
-    int bx = clampi((int)floorf(p.x * P.bsx - 0.0625f), 0, P.bnx - 1);
-    int by = clampi((int)floorf(p.y * P.bsy - 0.0625f), 0, P.bny - 1);
-    int bz = clampi((int)floorf(p.z * P.bsz - 0.0625f), 0, P.bnz - 1);
+    // clamp(floor(p*(n/8) - 1/16), 0, (n-1) >> 3).
+    int bx, by, bz;
+    if constexpr (FMED) {
+        // The clamp is taken in float (one v_med3_f32; a NaN comes out as 0 either way) and truncation of the clamped,
+        // non-negative value is its floor: four instructions per axis.
+        bx = (int)__builtin_amdgcn_fmed3f(p.x * P.bsx - 0.0625f, 0.0f, (float)(P.bnx - 1));
+        by = (int)__builtin_amdgcn_fmed3f(p.y * P.bsy - 0.0625f, 0.0f, (float)(P.bny - 1));
+        bz = (int)__builtin_amdgcn_fmed3f(p.z * P.bsz - 0.0625f, 0.0f, (float)(P.bnz - 1));
+    } else {
+        // (integer clamps: the 64-bit-address kernels sit at the register limit of five waves per SIMD and the float
+        // form costs them four more)
+        bx = clampi((int)floorf(p.x * P.bsx - 0.0625f), 0, P.bnx - 1);
+        by = clampi((int)floorf(p.y * P.bsy - 0.0625f), 0, P.bny - 1);
+        bz = clampi((int)floorf(p.z * P.bsz - 0.0625f), 0, P.bnz - 1);
+    }
     return __mul24(__mul24(bz, P.bny) + by, P.bnx) + bx;  // < 2^24 bricks per axis pair: 24-bit multiplies are exact
+}
+// distance-field byte of brick `bid` (SGPR base + 32-bit offset addressing)
+__device__ __forceinline__ unsigned dist_at(const MarchParams& P, int bid)
+{
+    return *(reinterpret_cast<const unsigned char*>(P.brick_dist) + (unsigned)bid);
 }
 // record of brick `bid`: the table is far below 4 GiB, so SGPR base + 32-bit byte offset addressing
 __device__ __forceinline__ float2 brick_record(const MarchParams& P, int bid)
@@ -860,8 +877,8 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                 Fetch1 F1;
                 float wfx = 0.0f, wfy = 0.0f, wfz = 0.0f;
                 if constexpr (SKIP) {
-                    D = P.brick_dist[brick_of(P, p)];
-                    Dq = P.brick_dist[brick_of(P, mk3(p.x + step.x, p.y + step.y, p.z + step.z))];
+                    D = dist_at(P, brick_of<OFF32>(P, p));
+                    Dq = dist_at(P, brick_of<OFF32>(P, mk3(p.x + step.x, p.y + step.y, p.z + step.z)));
                     asm volatile("" : "+v"(D));  // wait for D here; Dq stays in flight
                 }
                 const int lim = min(n_inside, P.steps_count);  // runs stay inside the provably-in-box prefix
@@ -879,14 +896,14 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                     if constexpr (SKIP) {
                         if (!have) {
                             if constexpr (kPipe) {
-                                if (stale) Dq = P.brick_dist[brick_of(P, pn)];  // first iteration after leaving tissue
+                                if (stale) Dq = dist_at(P, brick_of<OFF32>(P, pn));  // first iteration after leaving tissue
                                 stale = false;
                             }
                             // requested an iteration ago.  (The copy is spelled out so that it happens HERE and the new
                             // load can go into Dq's own register: a compiler-placed copy behind the load would wait.)
                             asm volatile("v_mov_b32 %0, %1" : "=v"(Dn) : "v"(Dq));
                             __builtin_amdgcn_sched_barrier(0);
-                            Dq = P.brick_dist[brick_of(P, pq)];
+                            Dq = dist_at(P, brick_of<OFF32>(P, pq));
                         }
                     }
                     if constexpr (kRun) {
@@ -913,8 +930,8 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                             }
                             i += mw;
                             blends += (unsigned)mw;
-                            D = P.brick_dist[brick_of(P, p)];
-                            Dq = P.brick_dist[brick_of(P, mk3(p.x + step.x, p.y + step.y, p.z + step.z))];
+                            D = dist_at(P, brick_of<OFF32>(P, p));
+                            Dq = dist_at(P, brick_of<OFF32>(P, mk3(p.x + step.x, p.y + step.y, p.z + step.z)));
                             asm volatile("" : "+v"(D));  // (and everything older); Dq stays in flight
                             have = false;
                             stale = false;
@@ -943,7 +960,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                                 // requested after this step's table texels, so waiting for the texels leaves those eight
                                 // loads in flight; the look-ahead byte is taken before them for the same reason.
                                 unsigned R = 0;
-                                if constexpr (SKIP) R = P.brick_dist[brick_of(P, pq)];
+                                if constexpr (SKIP) R = dist_at(P, brick_of<OFF32>(P, pq));
                                 TfFetch tq;
                                 f3 grad = mk3(0.0f, 0.0f, 0.0f);
                                 if constexpr (V == V_LIGHT) {
@@ -1018,8 +1035,8 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                                             adv = m;
                                             pn = q;
                                             if constexpr (V != V_BASIC && V != V_TF_CALIB) w = wq;
-                                            Dn = P.brick_dist[brick_of(P, pn)];
-                                            Dq = P.brick_dist[brick_of(P, mk3(pn.x + step.x, pn.y + step.y, pn.z + step.z))];
+                                            Dn = dist_at(P, brick_of<OFF32>(P, pn));
+                                            Dq = dist_at(P, brick_of<OFF32>(P, mk3(pn.x + step.x, pn.y + step.y, pn.z + step.z)));
                                             asm volatile("" : "+v"(Dn));
                                         }
                                     }

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void march_wtb_light_kernel(const MarchParams 
             int bid = brick_of(P, q);
             if (bid != cur_brick) {
                 cur_brick = bid;
-                cur_inert = P.brick_dist[bid] != 0;
+                cur_inert = dist_at(P, bid) != 0;
             }
             return cur_inert;
         } else {
