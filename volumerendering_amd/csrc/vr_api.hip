@@ -77,7 +77,8 @@ struct vr_ctx {
     int flavour = 0;
     int waves_per_block = 4;  // 1 or 4 (experiment knob VR_EXP_WAVES_PER_BLOCK)
     int only_tile = -1;       // experiment knob VR_EXP_ONLY_TILE
-    int prio_mode = 1;        // wave priority by remaining ray path (VR_EXP_PRIO=0 switches it off)
+    int prio_mode = 0;        // VR_EXP_PRIO=1: wave priority by remaining ray path (+2-3 % for one frame at a time,
+                              // -2 % with frames in flight, where nothing waits for the long rays)
     int n_cus = 256;          // compute units of the device
     int default_flavour = 0;  // what flavour 0 resolves to (experiment knob VR_EXP_FLAVOUR)
     int last_flavour = 0;     // the flavour the last launch resolved to
