@@ -208,12 +208,26 @@ __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
     c.fz = z - z0;
     // the same eight voxel indices as texel_pair() on each axis gives, built from one base index and three
     // strides that are 0 where the pair is clamped
+    const unsigned row = (unsigned)v.nx, slab = (unsigned)v.nx * (unsigned)v.ny;
+    const int tx = (int)x0, ty = (int)y0, tz = (int)z0;  // saturating conversions, NaN -> 0
+    const bool inner = (unsigned)tx < (unsigned)(v.nx - 1) && (unsigned)ty < (unsigned)(v.ny - 1) && (unsigned)tz < (unsigned)(v.nz - 1);
+    if (__ballot(!inner) == 0) {
+        // every ray of the packet that samples now has its cell strictly inside the volume: nothing to clamp
+        c.o000 = ((unsigned)tz * (unsigned)v.ny + (unsigned)ty) * row + (unsigned)tx;
+        c.o100 = c.o000 + 1u;
+        c.o010 = c.o000 + row;
+        c.o110 = c.o010 + 1u;
+        c.o001 = c.o000 + slab;
+        c.o101 = c.o001 + 1u;
+        c.o011 = c.o001 + row;
+        c.o111 = c.o011 + 1u;
+        return c;
+    }
     int i0, j0, k0;
     bool sx, sy, sz;
     texel_step(x0, v.nx, i0, sx);
     texel_step(y0, v.ny, j0, sy);
     texel_step(z0, v.nz, k0, sz);
-    const unsigned row = (unsigned)v.nx, slab = (unsigned)v.nx * (unsigned)v.ny;
     const unsigned dx = sx ? 1u : 0u, dy = sy ? row : 0u, dz = sz ? slab : 0u;
     c.o000 = ((unsigned)k0 * (unsigned)v.ny + (unsigned)j0) * row + (unsigned)i0;
     c.o100 = c.o000 + dx;
