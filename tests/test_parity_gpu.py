@@ -232,11 +232,19 @@ def test_skipping_with_hostile_values(ctx):
     u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
     tf = zero_prefix_tf(32, 3)
     for variant in (capi.BASIC, capi.LIGHT):
-        for flavour in (0, 1):
+        ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
+        for flavour in (0, 1, 5, 6, 8, 9, 11):  # every loop form and lanes-per-ray layout
             ctx.set_kernel_flavour(flavour)
             frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
-            ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
             assert same(frag, ref) and ns == n_ref, (variant, flavour)
+    # a huge (finite) colour: rgb * 0 would still be 0, but rgb * shade may overflow -> skipping is disabled as well
+    big = hr.default_color_tf(32).copy()
+    big[5, 0] = f32(3.0e38)
+    for flavour in (0, 6):
+        ctx.set_kernel_flavour(flavour)
+        frag, _, ns = vt.gpu_render(ctx, capi.LIGHT, u, [v], [(tf[0], big)])
+        ref, n_ref, _ = ob.render(capi.LIGHT, u, [v], [(tf[0], big)], W, H, nthreads=8)
+        assert same(frag, ref) and ns == n_ref and ctx.counters()[2] == ns
     ctx.set_kernel_flavour(0)
     # non-finite colour entry: 0 * inf = NaN would differ from a skipped sample -> skipping is disabled
     c = hr.default_color_tf(32).copy()
