@@ -617,8 +617,45 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
 template <int V, bool OFF32>
 __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst, f3 start)
 {
-    const Src s = sample_src<V, OFF32>(P, p, w, start, dst.w);
-    blend(s.rgb, s.a, dst);
+    if constexpr (V == V_LIGHT) {
+        // sample_src<V_LIGHT> + blend, written on (x, y) / (r, g) register pairs from the interpolation to the blend so
+        // that the packed instructions need no shuffling; per component the operations and their order are those of
+        // normalize3 / shade / blend.
+        Fetch4 q;
+        float fx, fy, fz;
+        fetch_rgba<OFF32>(P.vol[0], p, q, fx, fy, fz);
+        const v2f zw = interp_zw(q, fx, fy, fz);  // (gradient z, density)
+        const TfFetch tq = tf_fetch(P.tf[0], zw.y);
+        const v2f gxy = interp_xy(q, fx, fy, fz);
+        const v2f g2 = gxy * gxy;
+        const float inv_g = inv_sqrt_exact((g2.x + g2.y) + zw.x * zw.x);
+        const v2f Nxy = gxy * inv_g;
+        const float Nz = zw.x * inv_g;
+        v2f Lxy = v2f{P.light_pos[0] - w.x, P.light_pos[1] - w.y};
+        float Lz = P.light_pos[2] - w.z;
+        const v2f l2 = Lxy * Lxy;
+        const float inv_l = inv_sqrt_exact((l2.x + l2.y) + Lz * Lz);
+        Lxy = Lxy * inv_l;
+        Lz = Lz * inv_l;
+        const v2f nl = Nxy * Lxy;
+        const float m = max0((nl.x + nl.y) + Nz * Lz);
+        const v2f sh_rg = (v2f{P.light_dif[0], P.light_dif[1]} * m) * 2.5f + v2f{P.light_amb[0], P.light_amb[1]} * 0.5f;
+        const float sh_b = (P.light_dif[2] * m) * 2.5f + P.light_amb[2] * 0.5f;
+        const float opacity = lerpf(tq.o0, tq.o1, tq.fo);
+        const v2f c_rg = lerp2(v2f{tq.c0.x, tq.c0.y}, v2f{tq.c1.x, tq.c1.y}, tq.fc);
+        const float c_b = lerpf(tq.c0.z, tq.c1.z, tq.fc);
+        const v2f src_rg = (c_rg * sh_rg) * opacity;  // FrontToBackBlend: (rgb * a, a)
+        const float src_b = (c_b * sh_b) * opacity;
+        const float om = 1.0f - dst.w;
+        const v2f d_rg = src_rg * om + v2f{dst.x, dst.y};
+        dst.x = d_rg.x;
+        dst.y = d_rg.y;
+        dst.z = om * src_b + dst.z;
+        dst.w = om * opacity + dst.w;
+    } else {
+        const Src s = sample_src<V, OFF32>(P, p, w, start, dst.w);
+        blend(s.rgb, s.a, dst);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ work mapping
