@@ -386,19 +386,24 @@ __device__ __forceinline__ int padded_texel(float x0, int n)
 }
 __device__ __forceinline__ TfFetch tf_fetch(const DevTF& tf, float d)
 {
-    // the opacity and the colour texture are separate 1-D textures, each with its own resolution
+    // the opacity and the colour texture are separate 1-D textures, each with its own resolution; when the two are
+    // equal (every scene of the reference, until a preset of another size is loaded) index and weight are shared
     float xo = d * (float)tf.res_o - 0.5f;
     float xo0 = floorf(xo);
     TfFetch q;
     q.fo = xo - xo0;
-    float xc = d * (float)tf.res_c - 0.5f;
-    float xc0 = floorf(xc);
-    q.fc = xc - xc0;
+    const int jo = padded_texel(xo0, tf.res_o);
+    int jc = jo;
+    q.fc = q.fo;
+    if (tf.res_c != tf.res_o) {  // wave-uniform
+        float xc = d * (float)tf.res_c - 0.5f;
+        float xc0 = floorf(xc);
+        q.fc = xc - xc0;
+        jc = padded_texel(xc0, tf.res_c);
+    }
     // tables are far below 4 GiB: SGPR base + 32-bit byte offset
-    const unsigned ob = (unsigned)padded_texel(xo0, tf.res_o) << 2;
-    const unsigned cb = (unsigned)padded_texel(xc0, tf.res_c) << 4;
-    const char* po = reinterpret_cast<const char*>(tf.opacity) + ob;
-    const char* pc = reinterpret_cast<const char*>(tf.color) + cb;
+    const char* po = reinterpret_cast<const char*>(tf.opacity) + ((unsigned)jo << 2);
+    const char* pc = reinterpret_cast<const char*>(tf.color) + ((unsigned)jc << 4);
     q.o0 = reinterpret_cast<const float*>(po)[0];
     q.o1 = reinterpret_cast<const float*>(po)[1];
     q.c0 = reinterpret_cast<const float4*>(pc)[0];
