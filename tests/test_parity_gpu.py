@@ -446,7 +446,7 @@ def test_illustrative_shader_reads_alpha_and_camera(ctx):
                     args = dict(steps_count=count, step_size=step)
                     args.update(kw)
                     check(ctx, capi.ILLUSTRATIVE, hr.make_uniforms(W, H, **args), [v0, vols[1]], tfs, W, H)
-            assert ctx.last_kernel_flavour() == 6
+            assert ctx.last_kernel_flavour() in (5, 6, 9)  # one lane per ray, whatever the default resolves to
         thin = [(hr.thin_opacity_tf(64, top=0.05), tfs[0][1]), tfs[1]]
         check(ctx, capi.ILLUSTRATIVE, hr.make_uniforms(W, H, steps_count=count, step_size=step), vols, thin, W, H)
     finally:
