@@ -30,7 +30,7 @@ def main():
     app = host.Application(W, H, 0)
     variant, vols = bench.build_scene(app, host, synth, capi, a.workload, a.tf)
     ctx = app.context()
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [torch.cuda.Stream() for _ in range(4)]
     for fl in [int(x) for x in a.flavours.split(",")]:
         ctx.set_kernel_flavour(fl)
         for world in (1, 2, 4, 8):
@@ -46,19 +46,21 @@ def main():
                 per_rank.append(t)
             ran = ctx.last_kernel_flavour()
             nfl = ctx.tile_count(0, world) * capi.TILE * capi.TILE * 4
-            bufs = [torch.zeros(nfl, dtype=torch.float32, device="cuda") for _ in range(2)]
+            bufs = [torch.zeros(nfl, dtype=torch.float32, device="cuda") for _ in range(4)]
 
-            def burst(k):
+            def burst(k, depth):
                 for i in range(k):
-                    ctx.render_tiles_async(variant, 0, world, bufs[i & 1].data_ptr(), streams[i & 1].cuda_stream)
+                    ctx.render_tiles_async(variant, 0, world, bufs[i % depth].data_ptr(), streams[i % depth].cuda_stream)
                 torch.cuda.synchronize()
 
-            burst(6)
-            t0 = time.perf_counter()
-            burst(40)
-            two = (time.perf_counter() - t0) / 40 * 1e3
-            print(f"flavour {fl} (ran {ran}) world {world}: slowest rank's kernel {worst:.4f} ms, rank 0 with two in flight "
-                  f"{two:.4f} ms/frame   (ranks: " + " ".join(f"{t:.3f}" for t in per_rank) + ")", flush=True)
+            res = []
+            for depth in (2, 3, 4):
+                burst(8, depth)
+                t0 = time.perf_counter()
+                burst(120, depth)
+                res.append((time.perf_counter() - t0) / 120 * 1e3)
+            print(f"flavour {fl} (ran {ran}) world {world}: slowest rank's kernel {worst:.4f} ms; rank 0 with 2 / 3 / 4 in flight "
+                  + " / ".join(f"{t:.4f}" for t in res) + " ms/frame   (ranks: " + " ".join(f"{t:.3f}" for t in per_rank) + ")", flush=True)
 
 
 if __name__ == "__main__":
