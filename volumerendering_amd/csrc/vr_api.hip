@@ -70,7 +70,6 @@ struct vr_ctx {
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
     int cnt_blocks = 0;
-    hipStream_t cnt_stream = nullptr;
     unsigned long long* h_counters = nullptr;  // pinned [3]
     Timing tm;
     KernelRing ring;
@@ -499,7 +498,6 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     }
     // the per-block counts are summed and copied to the host when somebody asks for them (fetch_counters)
     c->cnt_pending = true;
-    c->cnt_stream = s;
     if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_end, s));
     c->tm.valid = frame_events;
     return VR_OK;
@@ -511,12 +509,15 @@ int fetch_counters(vr_ctx* c)
     if (!c->cnt_pending) return VR_OK;
     VR_HIP(c, hipSetDevice(c->device));
     if (c->cnt_blocks > 0) {
-        hipLaunchKernelGGL(sum_block_counts_kernel, dim3(1), dim3(256), 0, c->cnt_stream, c->d_block_counts[c->cnt_buf], c->cnt_blocks,
+        // the launch may have been enqueued on a stream of the caller's that no longer exists: wait for the device, then
+        // use the context's own stream
+        VR_HIP(c, hipDeviceSynchronize());
+        hipLaunchKernelGGL(sum_block_counts_kernel, dim3(1), dim3(256), 0, c->stream, c->d_block_counts[c->cnt_buf], c->cnt_blocks,
                            c->d_counters);
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipMemcpyAsync(c->h_counters, c->d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                 c->cnt_stream));
-        VR_HIP(c, hipStreamSynchronize(c->cnt_stream));
+                                 c->stream));
+        VR_HIP(c, hipStreamSynchronize(c->stream));
     } else {
         c->h_counters[0] = c->h_counters[1] = c->h_counters[2] = 0;
     }
@@ -1039,7 +1040,7 @@ int vr_last_block_trace(vr_ctx* c, uint64_t* out, int capacity)
 {
     if (!c || capacity < 0 || (capacity > 0 && !out)) return VR_ERR_INVALID_ARG;
     VR_HIP(c, hipSetDevice(c->device));
-    if (c->cnt_stream) VR_HIP(c, hipStreamSynchronize(c->cnt_stream));
+    VR_HIP(c, hipDeviceSynchronize());
     const int n = c->cnt_blocks < capacity ? c->cnt_blocks : capacity;
     if (n > 0)
         VR_HIP(c, hipMemcpy(out, c->d_block_counts[c->cnt_buf], (size_t)n * kBlockRecord * sizeof(unsigned long long),
