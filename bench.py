@@ -153,8 +153,15 @@ def main():
     device_index = int(os.environ.get("VR_BENCH_DEVICE", local_rank))
     backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(device_index)
+    # VR_BENCH_SELF_GATHER=1 (rehearsal): take the multi-rank code path -- tile render, RCCL gather, un-permute -- with
+    # a world of one, so that the RCCL calls and their stream ordering can be exercised on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("VR_BENCH_SELF_GATHER"))
     dist = None
-    if world > 1:
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist_mod
         dist = dist_mod
         if backend == "nccl":
@@ -181,14 +188,14 @@ def main():
     in_flight = args.in_flight
     # two streams and two sets of buffers, used alternately: frame k+1 starts while frame k's longest rays drain
     # (and, with N > 1, while frame k's tiles travel); --in-flight 1 keeps everything on one stream
-    nbuf = in_flight if world == 1 else min(in_flight, 2)
+    nbuf = in_flight if not multi else min(in_flight, 2)
     streams2 = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nbuf - 1)]
     for st in streams2[1:]:
         st.wait_stream(streams2[0])
     frames2 = [frame] + [torch.zeros_like(frame) for _ in range(nbuf - 1)]
     if nbuf == 1:
         streams2, frames2 = streams2 * 2, frames2 * 2
-    if world > 1:
+    if multi:
         # every frame's gather and un-permute completes inside the timed region
         my_tiles = [torch.zeros((tpr_max * tile_floats,), dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered = [torch.zeros((world, tpr_max * tile_floats), dtype=torch.float32, device="cuda") for _ in range(2)] \
@@ -203,7 +210,7 @@ def main():
             ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames2[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
 
     def run_frames(n_frames):
-        if world == 1:
+        if not multi:
             for k in range(n_frames):
                 ctx.render_async(variant, frames2[k % nbuf].data_ptr(), streams2[k % nbuf].cuda_stream)
             return
@@ -265,7 +272,7 @@ def main():
     # (samples the exact empty-space test skips need no voxel bytes and are not counted here, although they are
     # composited samples of the metric) + the 16 B/pixel frame write of the pixels it owns (ray set-up is fused
     # into the kernel: no ray-end image is read)
-    owned_px = W * H if world == 1 else ctx.tile_count(rank, world) * capi.TILE * capi.TILE
+    owned_px = W * H if not multi else ctx.tile_count(rank, world) * capi.TILE * capi.TILE
     alg_bytes = my_fetched * bs + 16 * owned_px
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms and kernel_ms > 0 else None
     traffic = None
@@ -306,7 +313,7 @@ def main():
         "config": {
             "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, "
                         f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
-            "partition": ("single GPU" if world == 1 else
+            "partition": ("single GPU" if not multi else
                           f"64x64 image tiles interleaved over {world} GPUs + RCCL gather") +
                          (f", {nbuf} frames in flight" if nbuf > 1 else ", one frame at a time"),
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
