@@ -9,19 +9,35 @@ workload is BASELINE.json configs[2] -- the one the metric is quoted on: ct-phan
 shade + opacity cut-off), default ramp TFs (R = 4096), 1/512 x 886 steps, camera distance 1.2 / yaw .6 / pitch .35.
 At N > 1 the same frame is image-tile partitioned (64x64 tiles, tile t owned by rank t mod N), each rank renders
 its tiles from its own replica of the volume and an RCCL gather over xGMI assembles the frame on rank 0
-("strong" scaling: total work fixed).  value = composited samples of the whole frame / wall time per frame.
+("strong" scaling: total work fixed).
 
-Rank 0 prints ONE JSON line; it also carries `roofline` (effective-gather bytes of the march kernel against the
-8 TB/s HBM peak, kernel time from HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on the
-host cores of this box on a bounded pixel sample of the same frame; N = 1 only).
+Two legs are timed in one run, W warm-up + exactly K timed frames each, bracketed by barrier + device synchronise:
+    serial      one frame at a time (the reference's interactive loop, Application.cpp:332-379): latency
+    overlapped  two frames in flight on two streams (the next frame fills the SIMDs the longest rays of the previous
+                one leave idle): throughput.  `value` / `ms_per_step` are this leg's; the serial leg is in `serial`.
+value = composited samples of the whole frame / wall time per frame.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+    roofline      HBM roofline of the march kernel from MEASURED fabric bytes (rocprofv3 PMC passes run by this script
+                  on the same scene: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) over the median HIP-event kernel
+                  time of the serial leg; the effective-gather figure (algorithmic bytes that L1/L2 mostly serve) and the
+                  VALU-issue occupancy are separate, clearly named fields
+    parity        the same frame rendered by the CPU oracle, compared with the GPU frame (max abs, bit equality, counts)
+    cpu_baseline  the oracle timed on the host cores of this box (all cores and one thread); N = 1 only
+    regimes       (C3 only) the four {exact-0 air, noisy air} x {default ramp, zero-prefix TF} numbers, serial leg
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,121 +47,163 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-
-# per-composited-sample algorithmic bytes: the f32 footprint of one trilinear cell
-BYTES_PER_SAMPLE = {"BASIC": 32, "LIGHT": 128, "VOLUME_MASK": 288, "THREE_FILES": 64, "MULTI_CTRT": 160, "TF_CALIB": 48,
-                    "ILLUSTRATIVE": 160}
+N_SIMDS = 256 * 4      # CUs x SIMDs per CU (same table)
 
 # which kernel a resolved flavour runs (include/vr.h, vr_set_kernel_flavour)
 KERNEL_OF_FLAVOUR = {1: "march_kernel (no skipping)", 2: "march_wtb_light_kernel", 3: "march_wtb_light_kernel",
                      6: "march_kernel (one lane per ray)", 7: "march_dp_kernel (4 lanes per ray)",
                      8: "march_dp_kernel (2 lanes per ray)", 9: "march_kernel (one lane per ray, pipelined)",
-                     10: "march_dp_kernel (4 lanes per ray, pipelined)", 11: "march_dp_kernel (2 lanes per ray, pipelined)"}
+                     10: "march_dp_kernel (4 lanes per ray, pipelined)", 11: "march_dp_kernel (2 lanes per ray, pipelined)",
+                     12: "march_den_kernel (density plane, one lane per ray)"}
 
-WORKLOADS = {
-    # name: (volume N, W, H, variant)
-    "C1": (64, 256, 256, "BASIC"),
-    "C2": (256, 1024, 1024, "BASIC"),
-    "C3": (512, 1920, 1080, "LIGHT"),
-    "C4": (512, 1920, 1080, "VOLUME_MASK"),
-    "C5": (1024, 3840, 2160, "LIGHT"),
-}
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"],
+              ["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"]]
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_scene(app, host, synth, capi, workload, tf_kind, vol_n=0):
-    """Generates the synthetic inputs, runs the reference's data-prep order through the C++ host classes and
-    starts the scene on `app` (uploads happen here, outside any timed region)."""
-    n, W, H, vname = WORKLOADS[workload]
-    full_n = n
-    n = vol_n or n
-    variant = capi.VARIANT_NAMES.index(vname)
-    t0 = time.time()
-    raw = synth.sphere_raw_fast(n) if workload == "C1" else synth.ct_phantom_raw_fast(n)
-    ct = host.VolumeFile.from_raw(raw)
-    del raw
-    vols = [ct]
-    if vname == "VOLUME_MASK":
-        mask = host.VolumeFile.from_vec4(synth.mask_vec4_fast(n), 1)
-        dose = host.VolumeFile.from_raw(synth.dose_raw())
-        vols = [mask, dose, ct]
-    app.OnStart(variant, vols)  # NormalizeData / PreComputeGradient in the scene's own order + uploads
-    if tf_kind in ("thin", "zero"):  # control points (0,0),(R-1,0.002): no ray terminates (SURVEY.md 8d)
-        for which in range(2 if vname == "VOLUME_MASK" else 1):
-            otf = app.scene_opacity_tf(which)
-            # "zero" (experiment): opacity identically 0 -> every sample is an identity blend: pure traversal cost
-            otf.SetControlPoint(1, otf.GetTextureResolution() - 1, 0.002 if tf_kind == "thin" else 0.0)
-    cam = app.camera()
-    cam.SetOrbit(0.35, 0.6, 1.2)
-    if vol_n:
-        app.set_params(steps_count=int(math.sqrt(3) * full_n), step_size=1.0 / full_n)
-    app.OnUpdate()
-    log(f"[bench] scene {workload} ({vname}, {n}^3, {W}x{H}, tf={tf_kind}) ready in {time.time() - t0:.1f}s")
-    return variant, vols
+# ------------------------------------------------------------------------------------------------ PMC child / passes
+def pmc_child(args):
+    """`bench.py --pmc-child`: what the rocprofv3 counter passes run -- the same scene, a few synchronous frames (one
+    launch at a time: counters of overlapping dispatches cannot be told apart), no torch, no timing."""
+    from volumerendering_amd import host, workloads as wl
+    n, W, H, vname = wl.WORKLOADS[args.workload]
+    with host.Application(W, H, 0) as app:
+        wl.build_scene(app, args.workload, args.tf, args.air, args.vol_n, quiet=True)
+        if args.flavour:
+            app.context().set_kernel_flavour(args.flavour)
+        for _ in range(4):
+            app.OnRender()
 
 
-def cpu_baseline(app, capi, variant, vols, W, H, budget_s=15.0):
-    """Times the CPU oracle (a port: plain-C restatement of the WGSL) on a bounded, regular sub-grid of the SAME
-    frame, on all host cores.  Reported baseline only; never part of the product path."""
+def live_pmc(args, passes=PMC_PASSES, timeout_s=150):
+    """Runs rocprofv3 --pmc passes (one counter group per run, with --kernel-trace only) on `bench.py --pmc-child` and
+    returns {counter: mean per march-kernel launch}.  Empty dict when rocprofv3 is unavailable or a pass fails."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {}, "rocprofv3 not found"
+    out = {}
+    keep = os.environ.get("VR_BENCH_PMC_DIR")  # keep the raw csv files there (for profiles/)
+    tmp = keep or tempfile.mkdtemp(prefix="vr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    note = ""
+    for i, ctrs in enumerate(passes):
+        d = os.path.join(tmp, f"pass{i}")
+        cmd = [prof, "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload, "--tf", args.tf, "--air", args.air,
+               "--flavour", str(args.flavour), "--vol-n", str(args.vol_n)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+        except Exception as e:  # noqa: BLE001
+            note += f"pass {ctrs[0]}: {type(e).__name__}; "
+            continue
+        if r.returncode != 0:
+            note += f"pass {ctrs[0]}: rc {r.returncode} {r.stderr.decode(errors='replace')[-160:]!r}; "
+            continue
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            per = {}
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if "march" not in row["Kernel_Name"]:
+                        continue
+                    per.setdefault(row["Counter_Name"], {}).setdefault(int(row["Dispatch_Id"]), 0.0)
+                    per[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
+            for name, dd in per.items():
+                vals = [dd[k] for k in sorted(dd)][1:] or list(dd.values())  # drop the first (cold) launch
+                out[name] = sum(vals) / len(vals)
+    if not keep:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, note
+
+
+# ------------------------------------------------------------------------------------------------ CPU oracle legs
+def oracle_legs(app, variant, vols, W, H, gpu_frame, gpu_samples, budget_s=25.0):
+    """The CPU oracle (a port: plain-C restatement of the WGSL) on the SAME frame: all host cores on the densest
+    regular pixel grid that fits the budget (the whole frame for C1-C4), compared pixel by pixel with the GPU frame,
+    and one thread on a sparser grid.  Checker and reported baseline only; never part of the product path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import host_ref as hr
     import oracle_binding as ob
+    from volumerendering_amd import workloads as wl
 
-    # threads actually used: the CPUs this process may run on, capped at the GPU box's per-GPU CPU share
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
-    u = app.uniforms()
-    uo = hr.Uniforms.from_buffer_copy(bytes(u))
-    volumes = [v.data() for v in vols]
-    tfs = []
-    for which in range(2 if len(vols) == 3 else 1):
-        tfs.append((app.scene_opacity_tf(which).table(), app.scene_color_tf(which).table()))
-    # calibrate the stride on a coarse grid, then size the sample for ~budget_s of wall time
-    stride = 32
-    value, sample = None, ""
-    for _ in range(3):
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ub, volumes, tfs = wl.oracle_inputs(app, vols)
+    uo = hr.Uniforms.from_buffer_copy(ub)
+
+    def grid(stride):
         ys, xs = np.meshgrid(np.arange(stride // 2, H, stride), np.arange(stride // 2, W, stride), indexing="ij")
-        pxy = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.int32)
+        return np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.int32)
+
+    def run(stride, threads):
+        pxy = grid(stride)
         t0 = time.perf_counter()
-        _, n = ob.render_pixels(variant, uo, volumes, tfs, W, H, pxy, nthreads=cores)
-        dt = time.perf_counter() - t0
-        value = n / dt / 1e9 if dt > 0 else 0.0
-        sample = (f"one pixel out of every {stride} x {stride} block of the {W}x{H} frame ({pxy.shape[0]} rays, {n} composited "
-                  f"samples, {dt:.2f} s)")
-        if dt >= budget_s / 4 or stride <= 2:
-            break
-        stride = max(2, int(stride / math.sqrt(min(16.0, (budget_s / 2) / max(dt, 1e-3)))))
-    return {"value": round(value, 6), "unit": "Gsamples/s", "cores": cores, "kind": "port", "sample": sample}
+        out, n = ob.render_pixels(variant, uo, volumes, tfs, W, H, pxy, nthreads=threads)
+        return pxy, out, n, time.perf_counter() - t0
+
+    # calibrate on 1 pixel of every 16 x 16, then the densest grid that fits the budget
+    _, _, n_c, dt_c = run(16, cores)
+    per_px = dt_c / max(1, len(grid(16)))
+    stride = 1
+    while stride < 16 and per_px * (W // stride) * (H // stride) > budget_s:
+        stride += 1
+    pxy, out, n_all, dt_all = run(stride, cores)
+    got = gpu_frame[pxy[:, 1], pxy[:, 0]]
+    bit_equal = bool(np.array_equal(got.view(np.uint32), out.view(np.uint32)))
+    with np.errstate(invalid="ignore"):
+        max_abs = float(np.nanmax(np.abs(got - out))) if out.size else 0.0
+    parity = {"max_abs": max_abs, "bit_equal": bit_equal, "pixels": int(pxy.shape[0]),
+              "of_frame": "whole frame" if stride == 1 else f"one pixel of every {stride} x {stride}",
+              "oracle_composited_samples": int(n_all), "tolerance": 1e-4}
+    if stride == 1:
+        parity["samples_equal"] = bool(n_all == gpu_samples)
+    # one thread: a grid sized for ~10 s from the all-core rate
+    rate1 = (n_all / dt_all) / cores if dt_all > 0 else 1.0
+    s1 = stride
+    while s1 < 64 and (n_all * (stride / s1) ** 2) / max(rate1, 1.0) > 10.0:
+        s1 += 1
+    p1, _, n_1, dt_1 = run(s1, 1)
+    base = {"value": round(n_all / dt_all / 1e9, 6), "unit": "Gsamples/s", "cores": cores, "kind": "port",
+            "implementation": "oracle/vr_oracle.c (scalar C restatement of the WGSL, pthread over pixels)",
+            "sample": f"{parity['of_frame']} of the {W}x{H} frame ({pxy.shape[0]} rays, {n_all} composited samples, {dt_all:.2f} s)",
+            "one_thread": {"value": round(n_1 / dt_1 / 1e9, 6), "cores": 1,
+                           "sample": f"one pixel of every {s1} x {s1} ({p1.shape[0]} rays, {n_1} composited samples, {dt_1:.2f} s)"}}
+    return parity, base
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)   # frames take ~0.5 ms: 200 of them still run in a blink, and the
-    ap.add_argument("--warmup", type=int, default=20)   # fill / drain of the two-frame pipeline stops mattering
-    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--tf", default="default", choices=["default", "thin", "zero"])
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--tf", default="default", choices=["default", "thin", "prefix", "zero"])
+    ap.add_argument("--air", default="exact0", choices=["exact0", "noisy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the air x TF regime table (C3)")
     ap.add_argument("--flavour", type=int, default=0)
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="frames in flight on one GPU: 2 = alternate two streams and two frame buffers, so that the next "
-                         "frame fills the machine while the longest rays of the previous one drain (N = 1 only)")
+                    help="frames in flight in the overlapped leg (1 = that leg is a second serial leg)")
     ap.add_argument("--exp-mode", type=int, default=0, help="experiment: fragmentMode 1-4 (ray set-up only)")
     ap.add_argument("--exp-steps", type=int, default=-1, help="experiment: override stepsCount")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     import torch
-    from volumerendering_amd import capi, host, synth
+    from volumerendering_amd import capi, host, workloads as wl
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     # VR_BENCH_DEVICE / VR_BENCH_BACKEND exist only to rehearse the N > 1 code path on a one-GPU box (all ranks on
@@ -170,9 +228,9 @@ def main():
             dist.init_process_group(backend=backend)
     comm_dev = "cuda" if backend == "nccl" else "cpu"
 
-    n, W, H, vname = WORKLOADS[args.workload]
+    n, W, H, vname = wl.WORKLOADS[args.workload]
     app = host.Application(W, H, device_index)
-    variant, vols = build_scene(app, host, synth, capi, args.workload, args.tf, args.vol_n)
+    variant, vols = wl.build_scene(app, args.workload, args.tf, args.air, args.vol_n)
     ctx = app.context()
     if args.flavour:
         ctx.set_kernel_flavour(args.flavour)
@@ -180,21 +238,14 @@ def main():
         app.set_params(fragment_mode=args.exp_mode, steps_count=args.exp_steps)
         app.OnUpdate()
     steps_count, step_size = app.stepping()
-    stream = torch.cuda.current_stream().cuda_stream
 
     tpr_max = ctx.tile_count(0, world)
     tile_floats = capi.TILE * capi.TILE * 4
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    in_flight = args.in_flight
-    # two streams and two sets of buffers, used alternately: frame k+1 starts while frame k's longest rays drain
-    # (and, with N > 1, while frame k's tiles travel); --in-flight 1 keeps everything on one stream
-    nbuf = in_flight if not multi else min(in_flight, 2)
-    streams2 = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nbuf - 1)]
-    for st in streams2[1:]:
-        st.wait_stream(streams2[0])
-    frames2 = [frame] + [torch.zeros_like(frame) for _ in range(nbuf - 1)]
-    if nbuf == 1:
-        streams2, frames2 = streams2 * 2, frames2 * 2
+    max_flight = 2 if multi else max(2, args.in_flight)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max_flight - 1)]
+    for st in streams[1:]:
+        st.wait_stream(streams[0])
+    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(max_flight)]
     if multi:
         # every frame's gather and un-permute completes inside the timed region
         my_tiles = [torch.zeros((tpr_max * tile_floats,), dtype=torch.float32, device="cuda") for _ in range(2)]
@@ -207,20 +258,20 @@ def main():
         if work is not None:
             work.wait()
         if rank == 0:
-            ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames2[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
 
-    def run_frames(n_frames):
+    def run_frames(n_frames, nbuf):
         if not multi:
             for k in range(n_frames):
-                ctx.render_async(variant, frames2[k % nbuf].data_ptr(), streams2[k % nbuf].cuda_stream)
+                ctx.render_async(variant, frames[k % nbuf].data_ptr(), streams[k % nbuf].cuda_stream)
             return
         pending = [None, None]  # per buffer set: (work handle,) of the frame that last used it
         for k in range(n_frames):
-            b = k & 1
-            with torch.cuda.stream(streams2[b]):
-                if pending[b] is not None:  # frame k-2 used these buffers: its tiles must have left before they are reused
+            b = k % nbuf
+            with torch.cuda.stream(streams[b]):
+                if pending[b] is not None:  # the previous user of these buffers: its tiles must have left before reuse
                     finish(b, pending[b][0])
-                ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), streams2[b].cuda_stream)
+                ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), streams[b].cuda_stream)
                 if backend == "nccl":
                     # RCCL over xGMI: every peer sends straight to the root (7 links in parallel, not a ring); the
                     # collective is ordered behind this stream's render and runs on RCCL's own stream
@@ -232,10 +283,12 @@ def main():
                         gathered[b].copy_(torch.stack(host_list))
                     work = None
                 pending[b] = (work,)
-        for b in ((n_frames & 1), ((n_frames + 1) & 1)):  # the older of the two outstanding frames first
+        order = [((n_frames + j) % nbuf) for j in range(nbuf)]  # the oldest outstanding frame first
+        for b in order:
             if pending[b] is not None:
-                with torch.cuda.stream(streams2[b]):
+                with torch.cuda.stream(streams[b]):
                     finish(b, pending[b][0])
+                pending[b] = None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -243,51 +296,109 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_frames(args.warmup)
-    sync_all()
-    ctx.reset_kernel_times()
-    t0 = time.perf_counter()
-    run_frames(args.steps)
-    sync_all()
-    dt = time.perf_counter() - t0
+    def timed_leg(nbuf, n_warm, n_steps, min_events=0):
+        """W warm-up + exactly K timed frames, barrier + synchronise on both sides; the MAX over ranks of the wall time.
+        Returns (seconds, HIP-event kernel durations of the timed launches [+ extra serial frames up to min_events])."""
+        run_frames(n_warm, nbuf)
+        sync_all()
+        ctx.reset_kernel_times()
+        t0 = time.perf_counter()
+        run_frames(n_steps, nbuf)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if n_steps < min_events:  # the median below wants >= 20 event-timed frames (outside the K-step region)
+            run_frames(min_events - n_steps, nbuf)
+            sync_all()
+        kt = ctx.kernel_times(min(max(n_steps, min_events), 256))
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kt
+
+    dt_serial, kt_serial = timed_leg(1, args.warmup, args.steps, min_events=20)
+    nbuf_over = min(args.in_flight, max_flight)
+    dt_over, kt_over = timed_leg(nbuf_over, args.warmup, args.steps)
 
     # composited samples / covered pixels / samples whose voxels were fetched, for this rank's share of the frame
     my_samples, my_covered, my_fetched = ctx.counters()
-    ktimes = ctx.kernel_times(min(args.steps, 256))
-    kernel_ms = float(np.mean(ktimes)) if len(ktimes) else float("nan")
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         s = torch.tensor([my_samples, my_covered, my_fetched], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_samples, covered, total_fetched = int(s[0].item()), int(s[1].item()), int(s[2].item())
     else:
         total_samples, covered, total_fetched = my_samples, my_covered, my_fetched
+    ran = ctx.last_kernel_flavour()
 
-    ms_per_step = dt / args.steps * 1e3
-    value = total_samples / (dt / args.steps) / 1e9
-    bs = BYTES_PER_SAMPLE[vname]
-    # dominant kernel = march_kernel; algorithmic bytes per launch = the samples this rank actually FETCHED * B_s
-    # (samples the exact empty-space test skips need no voxel bytes and are not counted here, although they are
-    # composited samples of the metric) + the 16 B/pixel frame write of the pixels it owns (ray set-up is fused
-    # into the kernel: no ray-end image is read)
+    def leg(dt, kt, nbuf):
+        ms = dt / args.steps * 1e3
+        return {"frames_in_flight": nbuf, "ms_per_step": round(ms, 4), "fps": round(1e3 / ms, 2),
+                "value": round(total_samples / (dt / args.steps) / 1e9, 3),
+                "fetched_gsamples_per_s": round(total_fetched / (dt / args.steps) / 1e9, 3),
+                "kernel_ms_median": round(float(np.median(kt)), 4) if len(kt) else None,
+                "kernel_ms_mean": round(float(np.mean(kt)), 4) if len(kt) else None, "kernel_events": int(len(kt))}
+
+    serial, over = leg(dt_serial, kt_serial, 1), leg(dt_over, kt_over, nbuf_over)
+    kernel_ms = serial["kernel_ms_median"]
+    bs = wl.BYTES_PER_SAMPLE[vname]
     owned_px = W * H if not multi else ctx.tile_count(rank, world) * capi.TILE * capi.TILE
-    alg_bytes = my_fetched * bs + 16 * owned_px
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms and kernel_ms > 0 else None
+    alg_fetched = my_fetched * bs + 16 * owned_px   # what the kernel's loads ask for (mostly served by L1 / L2)
+    alg_composited = my_samples * bs + 16 * owned_px  # SURVEY 8d's figure: every composited sample priced as a fetch
+    vol_bytes = sum(int(np.prod(v.GetSize())) * 16 for v in vols)
+
+    gpu_frame = frames[0].cpu().numpy() if rank == 0 else None  # the serial leg's / the oldest buffer's frame
+
+    # ---- roofline: measured fabric bytes (rocprofv3 PMC passes on the same scene, launched from here) -------------
+    pmc, pmc_note = ({}, "skipped")
+    if rank == 0 and world == 1 and not multi and not args.no_live_pmc:
+        t0 = time.time()
+        pmc, pmc_note = live_pmc(args)
+        log(f"[bench] rocprofv3 counter passes: {time.time() - t0:.1f}s {pmc_note}")
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-    if os.path.exists(tpath):
+    traffic_source = None
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        traffic_source = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this script on the same scene, one launch at "
+                          "a time; (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 FETCH_SIZE correction; counts "
+                          "Infinity-Cache hits too: an upper estimate of HBM bytes)")
+    else:
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
         try:
             tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and tj.get("tf") == args.tf and tj.get("n_gpus") == world:
+            if (tj.get("workload"), tj.get("tf"), tj.get("air", "exact0"), tj.get("n_gpus")) == (args.workload, args.tf, args.air, world):
                 traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    ran = ctx.last_kernel_flavour()
+                traffic_source = f"STALE: committed profiles/pmc_traffic_latest.json (live passes: {pmc_note})"
+        except Exception:  # noqa: BLE001
+            pass
+    achieved = traffic / (kernel_ms * 1e-3) / 1e9 if (traffic and kernel_ms) else None
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
+        "kernel": KERNEL_OF_FLAVOUR.get(ran, "march_kernel"), "kernel_ms": kernel_ms,
+        "kernel_ms_is": "median HIP-event duration of the serial leg's launches (>= 20), on the launch stream",
+        "frac_overlapped": round(traffic / (over["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+        "bytes_per_sample": bs,
+        "effective_gather": {
+            "note": "algorithmic bytes the loads ask for; L1 / L2 serve most of them, so this is NOT a roofline fraction",
+            "fetched_bytes_per_launch": alg_fetched, "composited_bytes_per_launch": alg_composited,
+            "fetched_gbs": round(alg_fetched / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms else None,
+            "composited_gbs": round(alg_composited / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms else None},
+        "compulsory_floor_bytes": vol_bytes + 16 * owned_px,
+        "compulsory_floor_note": "stored volume bytes + frame write; exact empty-space skipping never touches inert bricks, so "
+                                 "measured traffic may be below this",
+    }
+    if "SQ_ACTIVE_INST_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+        cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
+        roofline["valu"] = {
+            "insts_per_launch": pmc.get("SQ_INSTS_VALU"), "active_quad_cycles": pmc["SQ_ACTIVE_INST_VALU"],
+            "gpu_cycles_per_launch": cyc,
+            "busy_frac": round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * cyc), 4),
+            "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of the launch's SIMD-cycles "
+                    "spent issuing vector ALU work (serial, profiled launches)"}
+        roofline["limiter"] = "valu-issue + longest-ray tail" if roofline["valu"]["busy_frac"] > (roofline["frac"] or 0) else "hbm"
+    if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
+        roofline["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
     # second denominator (SURVEY.md 8d): what a plain device-to-device copy reaches on this GPU right now
-    d2d_gbs = None
     if rank == 0:
         try:
             src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")  # 1 GiB
@@ -300,49 +411,84 @@ def main():
                 dstb.copy_(src)
             e1.record()
             torch.cuda.synchronize()
-            d2d_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # bytes read + written
+            d2d = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # bytes read + written
+            roofline["d2d_copy_gbs"] = round(d2d, 1)
+            roofline["frac_of_d2d_copy"] = round(achieved / d2d, 4) if achieved else None
             del src, dstb
-        except Exception:
-            d2d_gbs = None
+        except Exception:  # noqa: BLE001
+            pass
 
+    part = "single GPU" if not multi else f"64x64 image tiles interleaved over {world} GPUs + " + \
+        ("RCCL gather (torch.distributed nccl backend)" if backend == "nccl" else f"{backend} gather through host memory (rehearsal)")
     out = {
-        "metric": "Gsamples/s", "value": round(value, 4), "unit": "Gsamples/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "fps": round(1e3 / ms_per_step, 3),
+        "metric": "Gsamples/s", "value": over["value"], "unit": "Gsamples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": over["ms_per_step"], "fps": over["fps"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, "
+            "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, air {args.air}, "
                         f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
-            "partition": ("single GPU" if not multi else
-                          f"64x64 image tiles interleaved over {world} GPUs + RCCL gather") +
-                         (f", {nbuf} frames in flight" if nbuf > 1 else ", one frame at a time"),
+            "partition": part, "value_is": f"overlapped leg ({over['frames_in_flight']} frames in flight); one frame at a time in `serial`",
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
             "covered_pixels": covered, "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
         },
-        "roofline": {
-            "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-            "kernel": KERNEL_OF_FLAVOUR.get(ran, "march_kernel"), "kernel_ms": round(kernel_ms, 4), "bytes_per_sample": bs,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            # with two frames in flight two launches overlap: each one's own duration (kernel_ms, what rocprofv3 reports
-            # too) is longer than the time the GPU spends per frame; the rate of the overlapped pair is given as well
-            "d2d_copy_gbs": round(d2d_gbs, 1) if d2d_gbs else None,
-            "frac_of_d2d_copy": round(achieved / d2d_gbs, 4) if (achieved and d2d_gbs) else None,
-            "launches_in_flight": nbuf,
-            "achieved_per_frame_time": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-        },
+        "serial": serial, "overlapped": over, "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(app, capi, variant, vols, W, H)
+
+    # ---- the regime table (C3): {exact-0 air, noisy air} x {default ramp, zero-prefix TF}, serial leg -------------
+    if rank == 0 and not multi and args.workload == "C3" and not args.no_regimes and not args.vol_n:
+        current = (args.air, args.tf)
+
+        def scene(air, tf):
+            nonlocal app, variant, vols, ctx, current
+            if current == (air, tf):
+                return
+            if current == (air, "default") and tf != "default":
+                wl.apply_tf(app, vname, tf)  # same volume: edit the table through the control-point surface
+                app.OnUpdate()
+            else:
+                app.close()
+                vols = None
+                app = host.Application(W, H, device_index)
+                variant, vols = wl.build_scene(app, "C3", tf, air, quiet=True)
+                ctx = app.context()
+                if args.flavour:
+                    ctx.set_kernel_flavour(args.flavour)
+            current = (air, tf)
+
+        regimes = []
+        for air in wl.AIR_KINDS:
+            for tf in ("default", "prefix"):
+                scene(air, tf)
+                for _ in range(3):
+                    ctx.render_async(variant, frames[1].data_ptr(), streams[0].cuda_stream)
+                torch.cuda.synchronize()
+                ctx.reset_kernel_times()
+                for _ in range(20):
+                    ctx.render_async(variant, frames[1].data_ptr(), streams[0].cuda_stream)
+                torch.cuda.synchronize()
+                ms = float(np.median(ctx.kernel_times(20)))
+                cs, _, fs = ctx.counters()
+                regimes.append({"air": air, "tf": tf, "kernel_ms": round(ms, 4), "composited_gsamples_per_s": round(cs / ms / 1e6, 2),
+                                "fetched_gsamples_per_s": round(fs / ms / 1e6, 2), "composited": cs, "fetched": fs,
+                                "kernel_flavour_resolved": ctx.last_kernel_flavour()})
+        out["regimes"] = regimes
+        out["regimes_note"] = ("one frame at a time, median HIP-event kernel ms of 20 frames; noisy air = raw 0..80 outside the body; "
+                               "prefix = preset-style opacity table with a real zero prefix (workloads.py)")
+        scene(args.air, args.tf)  # the CPU legs below want the headline scene again
+
+    if rank == 0 and world == 1 and not multi and not args.no_cpu_baseline:
+        parity, base = oracle_legs(app, variant, vols, W, H, gpu_frame, total_samples)
+        out["parity"] = parity
+        out["cpu_baseline"] = base
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and os.environ.get("VR_BENCH_CHECK_FRAME"):
         # rehearsal aid: the gathered frame must equal a single-rank render of the same scene, bit for bit
-        ctx.render_async(variant, 0, stream)
+        ctx.render_async(variant, 0, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         ref, _, _ = ctx.download()
-        same = all(bool(np.array_equal(ref.view(np.uint32), f.cpu().numpy().view(np.uint32))) for f in frames2)
+        same = all(bool(np.array_equal(ref.view(np.uint32), f.cpu().numpy().view(np.uint32))) for f in frames[:2])
         out["config"]["frame_equals_single_rank_render"] = same
     if rank == 0:
         print(json.dumps(out), flush=True)

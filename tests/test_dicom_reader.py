@@ -104,3 +104,49 @@ def test_dicom_series_renders_like_raw(tmp_path):
             app.OnUpdate(); app.OnRender()
             frames.append(app.ReadFrame()[0])
     assert np.array_equal(vt.bits(frames[0]), vt.bits(frames[1])) and frames[0][..., 3].max() > 0
+
+
+def test_slice_with_other_dimensions_or_short_pixel_data_is_rejected(tmp_path):
+    """The reference asserts vec.size() == X*Y*frames per file (DicomReader.cpp:238,246); here the reader throws, so that a
+    volume whose declared size exceeds its data can never reach vr_volume_upload (heap over-read otherwise)."""
+    raw = synth.ct_phantom_raw(12)[:4]
+    d = tmp_path / "bad_dims"
+    d.mkdir()
+    for k in range(4):
+        px = raw[k] if k != 2 else raw[k][:6]                  # slice 3 is 6 x 12 instead of 12 x 12
+        dw.write_slice(str(d / f"s{k}.dcm"), px, rows=px.shape[1], cols=px.shape[0], instance=k + 1)
+    with pytest.raises(IOError, match="expected 144"):
+        host.VolumeFile.from_dicom(str(d))
+    d2 = tmp_path / "short"
+    d2.mkdir()
+    for k in range(3):
+        px = raw[k] if k != 1 else raw[k].ravel()[:100]        # Rows x Columns say 144 values, PixelData holds 100
+        dw.write_slice(str(d2 / f"s{k}.dcm"), px, rows=12, cols=12, instance=k + 1)
+    with pytest.raises(IOError, match="holds 100 values"):
+        host.VolumeFile.from_dicom(str(d2))
+    f = str(tmp_path / "frames.dcm")                           # multi-frame file announcing 5 frames, carrying 4
+    dw.write_slice(f, raw, rows=12, cols=12, frames=5)
+    with pytest.raises(IOError, match="expected 720"):
+        host.VolumeFile.from_dicom(f)
+    z = str(tmp_path / "zero.dcm")
+    dw.write_slice(z, raw[0][:0], rows=0, cols=12)
+    with pytest.raises(IOError):
+        host.VolumeFile.from_dicom(z)
+
+
+def test_deeply_nested_items_and_missing_meta_group_are_rejected(tmp_path):
+    import struct
+    ts = "1.2.840.10008.1.2.1"
+    meta = dw.element(0x00020010, "UI", ts, True)
+    # 100 000 nested undefined-length items: would recurse once per level without the depth limit
+    depth = 100000
+    open_seq = dw.element(0x00081140, "SQ", b"", True, undefined_len=True) + struct.pack("<HHI", 0xFFFE, 0xE000, 0xFFFFFFFF)
+    body = open_seq * depth
+    f = tmp_path / "nested.dcm"
+    f.write_bytes(b"\0" * 128 + b"DICM" + meta + dw.element(0x00080060, "CS", "CT", True) + body)
+    with pytest.raises(IOError, match="nested too deeply"):
+        host.VolumeFile.from_dicom(str(f))
+    g = tmp_path / "nometa.dcm"                                # DICM prefix, then a data set without any (0002,xxxx) element
+    g.write_bytes(b"\0" * 128 + b"DICM" + dw.element(0x00080060, "CS", "CT", True))
+    with pytest.raises(IOError, match="no file meta information"):
+        host.VolumeFile.from_dicom(str(g))

@@ -176,3 +176,38 @@ def test_volume_mask_scene_from_dicom_files(tmp_path):
         app.OnRender()
         frag0, _, _ = app.ReadFrame()
         assert not np.array_equal(frag, frag0)
+
+
+def test_prepare_on_device_uses_the_files_cached_maximum(tmp_path):
+    """DICOM input: GetMaxNumber() is LargestPixelValue, which need not be the data maximum.  The on-device preparation
+    must divide by it exactly as NormalizeData() does (not by the maximum found in the uploaded voxels)."""
+    import dicom_writer as dw
+    W, H, n = 96, 64, 16
+    raw = synth.ct_phantom_raw(n)
+    d = tmp_path / "series"
+    d.mkdir()
+    for k in range(n):
+        dw.write_slice(str(d / f"s{k:03d}.dcm"), raw[k], rows=n, cols=n, instance=k + 1, position=(0, 0, float(k)), largest=4000)
+    frames = []
+    for on_device in (False, True):
+        vf = host.VolumeFile.from_dicom(str(d))
+        assert vf.GetMaxNumber() == 4000 and int(raw.max()) != 4000
+        with host.Application(W, H, 0) as app:
+            app.OnStart(capi.LIGHT, [vf], tf_res=256, prepare_on_device=on_device)
+            app.camera().SetOrbit(0.35, 0.6, 1.2)
+            app.OnUpdate()
+            app.OnRender()
+            frag, _, samples = app.ReadFrame()
+            frames.append((frag, samples))
+            assert vf.GetDataRange() == 4000
+            assert vf.IsNormalized() == (not on_device)  # on-device preparation leaves the host voxels as loaded
+    assert frames[0][1] == frames[1][1] and frames[0][1] > 0
+    assert np.array_equal(vt.bits(frames[0][0]), vt.bits(frames[1][0]))
+
+
+def test_scene_start_fails_loudly_when_an_upload_fails():
+    """Upload / preparation return codes reach the caller of OnStart (an empty volume cannot be uploaded)."""
+    with host.Application(32, 32, 0) as app:
+        empty = host.VolumeFile.from_vec4(np.zeros((0, 4, 4, 4), dtype=np.float32), 1)
+        with pytest.raises(capi.VrError):
+            app.OnStart(capi.BASIC, [empty])

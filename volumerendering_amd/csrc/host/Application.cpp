@@ -21,15 +21,21 @@ Application::~Application()
     vr_destroy(p_Ctx);
 }
 
-void Application::OnStart(std::unique_ptr<MiniApp> app)
+int Application::OnStart(std::unique_ptr<MiniApp> app)
 {
     p_App = std::move(app);
-    if (!p_Ctx || !p_App) return;
+    if (!p_Ctx || !p_App) return VR_ERR_NOT_READY;
     p_App->SetPrepareOnDevice(m_PrepareOnDevice);
     p_App->OnStart(p_Ctx);
+    if (p_App->StartStatus() != VR_OK) {  // an upload or a device-preparation call failed (out of memory, bad size ...)
+        m_Error = vr_last_error(p_Ctx);
+        if (m_Error.empty()) m_Error = "scene start failed: volume data does not match its declared size";
+        return p_App->StartStatus();
+    }
     // "Using MiniApp's required step size / count" (Application.cpp:74-84)
     if (p_App->GetStepSize() != 0.0f) m_StepSize = p_App->GetStepSize();
     if (p_App->GetStepsCount() != 0) m_StepsCount = p_App->GetStepsCount();
+    return VR_OK;
 }
 
 int Application::OnUpdate()

@@ -24,7 +24,7 @@ public:
     bool Ok() const { return p_Ctx != nullptr; }
     const std::string& LastError() const { return m_Error; }
 
-    void OnStart(std::unique_ptr<MiniApp> app);  // scene selection + "use the MiniApp's step parameters" (:69-84)
+    int OnStart(std::unique_ptr<MiniApp> app);   // scene selection + "use the MiniApp's step parameters" (:69-84)
     int OnUpdate();                              // rewrites every uniform (:96-119) and lets the scene re-upload TFs
     int OnRender();                              // ray end pass + volume pass
     int OnFrame() { int rc = OnUpdate(); return rc != VR_OK ? rc : OnRender(); }

@@ -23,6 +23,8 @@ public:
     virtual void OnEnd() {}
     virtual int Variant() const = 0;         // which WGSL shader the scene attaches
     virtual const Light* GetLight() const { return nullptr; }
+    // first failure of an upload / device-preparation call made by OnStart (VR_OK if none): Application::OnStart returns it
+    int StartStatus() const { return m_Status; }
 
     void ComputeRecommendedSteppingParams(const VolumeFile& file)
     {
@@ -41,11 +43,20 @@ public:
     std::tuple<float, float, float> GetBBoxSize() const { return m_BBoxSize; }
 
 protected:
-    static void Upload(vr_ctx* ctx, int slot, const VolumeFile& f)
+    // records the first failing status of OnStart's calls into the ray-marcher
+    int Check(int rc)
+    {
+        if (rc != VR_OK && m_Status == VR_OK) m_Status = rc;
+        return rc;
+    }
+    int Upload(vr_ctx* ctx, int slot, const VolumeFile& f)
     {
         auto [x, y, z] = f.GetSize();
-        vr_volume_upload(ctx, slot, static_cast<const float*>(f.GetVoidPtr()), x, y, z);
+        // vr_volume_upload copies x*y*z vec4 from the pointer: a file whose declared size exceeds its data must not get there
+        if (f.GetVecReference().size() != static_cast<size_t>(x) * y * z) return Check(VR_ERR_INVALID_ARG);
+        return Check(vr_volume_upload(ctx, slot, static_cast<const float*>(f.GetVoidPtr()), x, y, z));
     }
+    int m_Status = VR_OK;
     bool m_PrepareOnDevice = false;
     float m_StepSize = 0.0f;
     int m_StepsCount = 0;

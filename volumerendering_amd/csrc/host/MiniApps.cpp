@@ -8,8 +8,11 @@ void BasicVolumeApp::OnStart(vr_ctx* ctx)
 {
     const bool onDevice = m_PrepareOnDevice && !p_Ct->IsNormalized();
     if (onDevice) {
+        // the divisor is the file's cached maximum (for DICOM input LargestPixelValue, which need not be the data maximum),
+        // exactly what NormalizeData() below would use
         Upload(ctx, 0, *p_Ct);
-        vr_volume_normalize(ctx, 0, 0, nullptr);
+        int used = 0;
+        if (Check(vr_volume_normalize(ctx, 0, static_cast<int>(p_Ct->GetMaxNumber()), &used)) == VR_OK) p_Ct->SetDeviceNormalization(used);
     } else {
         p_Ct->NormalizeData();
     }
@@ -34,8 +37,9 @@ void BasicVolLightApp::OnStart(vr_ctx* ctx)
     const bool onDevice = m_PrepareOnDevice && !p_Ct->IsNormalized() && !p_Ct->HasGradient();
     if (onDevice) {
         Upload(ctx, 0, *p_Ct);
-        vr_volume_normalize(ctx, 0, 0, nullptr);
-        vr_volume_precompute_gradient(ctx, 0, 0);
+        int used = 0;
+        if (Check(vr_volume_normalize(ctx, 0, static_cast<int>(p_Ct->GetMaxNumber()), &used)) == VR_OK) p_Ct->SetDeviceNormalization(used);
+        Check(vr_volume_precompute_gradient(ctx, 0, 0));
     } else {
         p_Ct->NormalizeData();
         p_Ct->PreComputeGradient();

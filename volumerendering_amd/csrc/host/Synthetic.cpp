@@ -34,8 +34,10 @@ inline double sq(double v) { return v * v; }
 extern "C" {
 
 // nested ellipsoids: air 0 / soft tissue 1000-1100 / bone shell 2500-3000 / interior 1040, + noise in [-40, 40]
-// from xorshift32(0x5EED ^ voxel index) inside the body; 12-bit values
-void vrh_synth_ct_phantom(int n, uint16_t* out)
+// from xorshift32(0x5EED ^ voxel index) inside the body; 12-bit values.  air_noise != 0: the air outside the body
+// carries the same generator's noise as raw 0..80 -- what a scanner delivers (stored CT values of air are not an
+// exact constant), so that nothing about the volume is exactly zero.
+void vrh_synth_ct_phantom_air(int n, int air_noise, uint16_t* out)
 {
     const double c = (n - 1) / 2.0, h = n / 2.0;
     par_z(n, [&](int z0, int z1) {
@@ -52,12 +54,14 @@ void vrh_synth_ct_phantom(int n, uint16_t* out)
                     if (inner) val = 1040.0;
                     const uint32_t idx = (uint32_t)(((uint64_t)z * n + y) * n + x);
                     const double noise = (double)((int64_t)(xorshift32(0x5EEDu ^ idx) % 81u) - 40);
-                    val = body ? val + noise : 0.0;
+                    val = body ? val + noise : (air_noise ? noise + 40.0 : 0.0);
                     val = std::nearbyint(val);
                     out[((size_t)z * n + y) * n + x] = (uint16_t)std::min(4095.0, std::max(0.0, val));
                 }
     });
 }
+
+void vrh_synth_ct_phantom(int n, uint16_t* out) { vrh_synth_ct_phantom_air(n, 0, out); }
 
 // sphere-N: round(4095 * max(0, 1 - |p - c| / (0.45 N)))
 void vrh_synth_sphere(int n, uint16_t* out)

@@ -31,6 +31,9 @@ public:
     void AverageGradient(int kernelSize);                 // VolumeFile.cpp:119-163 (computes and discards: a no-op)
     void NormalizeData(int normalizationValue = 0);       // VolumeFile.cpp:165-184
 
+    // The device copy was normalised by `value` (MiniApp::SetPrepareOnDevice) while these host voxels stay as loaded:
+    // GetDataRange() then reports what NormalizeData() would have recorded; IsNormalized() keeps describing the host data.
+    void SetDeviceNormalization(int value) { m_NormalizationValue = value; }
     bool IsNormalized() const { return m_IsNormalized; }
     bool HasGradient() const { return m_HasGradient; }
     [[nodiscard]] Size GetSize() const { return m_Size; }

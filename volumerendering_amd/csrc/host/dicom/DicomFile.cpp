@@ -39,7 +39,11 @@ bool DicomFile::Load()
     }
     // file meta information (group 0002) is always Explicit VR Little Endian
     size_t pos = 132;
-    if (!ParseDataset(pos, m_Bytes.size(), /*explicitVr=*/true, /*topLevel=*/true, &pos)) return false;
+    if (!ParseDataset(pos, m_Bytes.size(), /*explicitVr=*/true, /*topLevel=*/true, /*metaPass=*/true, 0, &pos)) return false;
+    if (m_Elements.empty()) {
+        m_Error = "no file meta information (group 0002) behind the DICM prefix";
+        return false;
+    }
     std::string ts = GetString(tags::kTransferSyntaxUID);
     bool explicitVr;
     if (ts == "1.2.840.10008.1.2.1") explicitVr = true;
@@ -50,7 +54,7 @@ bool DicomFile::Load()
     }
     m_DatasetStart = pos;
     m_ExplicitVr = explicitVr;
-    return ParseDataset(pos, m_Bytes.size(), explicitVr, true, &pos);
+    return ParseDataset(pos, m_Bytes.size(), explicitVr, /*topLevel=*/true, /*metaPass=*/false, 0, &pos);
 }
 
 namespace {
@@ -73,12 +77,16 @@ bool DicomFile::Walk(Visitor& visitor) const
     if (m_Bytes.empty() || m_DatasetStart == 0) return false;
     size_t pos = m_DatasetStart;
     std::string err;
-    return WalkDataset(&pos, m_Bytes.size(), false, visitor, &err);
+    return WalkDataset(&pos, m_Bytes.size(), false, 0, visitor, &err);
 }
 
 // Elements from *pos to `end` (or to the item delimiter when inItem and the item has undefined length).
-bool DicomFile::WalkDataset(size_t* pos, size_t end, bool inItem, Visitor& visitor, std::string* err) const
+bool DicomFile::WalkDataset(size_t* pos, size_t end, bool inItem, int depth, Visitor& visitor, std::string* err) const
 {
+    if (depth > kMaxDepth) {
+        *err = "sequences nested too deeply";
+        return false;
+    }
     while (*pos + 8 <= end) {
         const unsigned char* p = m_Bytes.data() + *pos;
         const Tag tag = (static_cast<Tag>(rd16(p)) << 16) | rd16(p + 2);
@@ -136,12 +144,12 @@ bool DicomFile::WalkDataset(size_t* pos, size_t end, bool inItem, Visitor& visit
             }
             visitor.BeginItem(tag, index);
             if (ilen == kUndefined) {
-                if (!WalkDataset(pos, seqEnd, true, visitor, err)) return false;
+                if (!WalkDataset(pos, seqEnd, true, depth + 1, visitor, err)) return false;
             } else {
                 size_t ipos = *pos;
                 const size_t iend = ipos + ilen;
                 if (iend > seqEnd) return false;
-                if (ipos < iend && !WalkDataset(&ipos, iend, false, visitor, err)) return false;
+                if (ipos < iend && !WalkDataset(&ipos, iend, false, depth + 1, visitor, err)) return false;
                 *pos = iend;
             }
             visitor.EndItem(tag, index);
@@ -155,9 +163,12 @@ bool DicomFile::WalkDataset(size_t* pos, size_t end, bool inItem, Visitor& visit
 
 // Parses elements from pos; at top level it stops after the meta group when asked to switch syntax (group > 0002
 // seen while parsing the meta header), otherwise at `end` or at an item delimiter (nested use).
-bool DicomFile::ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLevel, size_t* stop)
+bool DicomFile::ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLevel, bool metaPass, int depth, size_t* stop)
 {
-    const bool metaPass = topLevel && m_Elements.empty();
+    if (depth > kMaxDepth) {
+        m_Error = "sequences nested too deeply";
+        return false;
+    }
     while (pos + 8 <= end) {
         const unsigned char* p = m_Bytes.data() + pos;
         const Tag tag = (static_cast<Tag>(rd16(p)) << 16) | rd16(p + 2);
@@ -188,7 +199,7 @@ bool DicomFile::ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLe
         }
         pos += header;
         if (isSeq || (length == kUndefined && tag != tags::kPixelData)) {
-            if (!SkipSequence(&pos, end, length, explicitVr)) return false;
+            if (!SkipSequence(&pos, end, length, explicitVr, depth)) return false;
             continue;
         }
         if (length == kUndefined) {
@@ -206,7 +217,7 @@ bool DicomFile::ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLe
     return true;
 }
 
-bool DicomFile::SkipSequence(size_t* pos, size_t end, std::uint32_t length, bool explicitVr)
+bool DicomFile::SkipSequence(size_t* pos, size_t end, std::uint32_t length, bool explicitVr, int depth)
 {
     if (length != kUndefined) {
         if (*pos + length > end) {
@@ -235,7 +246,7 @@ bool DicomFile::SkipSequence(size_t* pos, size_t end, std::uint32_t length, bool
             *pos += len;
         } else {
             size_t stop = *pos;
-            if (!ParseDataset(*pos, end, explicitVr, /*topLevel=*/false, &stop)) return false;
+            if (!ParseDataset(*pos, end, explicitVr, /*topLevel=*/false, /*metaPass=*/false, depth + 1, &stop)) return false;
             *pos = stop;
         }
     }

@@ -68,9 +68,12 @@ private:
         size_t offset = 0;
         std::uint32_t length = 0;
     };
-    bool ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLevel, size_t* stop);
-    bool SkipSequence(size_t* pos, size_t end, std::uint32_t length, bool explicitVr);
-    bool WalkDataset(size_t* pos, size_t end, bool inItem, Visitor& visitor, std::string* err) const;
+    // depth = nesting level of undefined-length items / sequences; beyond kMaxDepth the file is rejected (a crafted file of
+    // nested items must not be able to exhaust the stack)
+    static constexpr int kMaxDepth = 64;
+    bool ParseDataset(size_t pos, size_t end, bool explicitVr, bool topLevel, bool metaPass, int depth, size_t* stop);
+    bool SkipSequence(size_t* pos, size_t end, std::uint32_t length, bool explicitVr, int depth);
+    bool WalkDataset(size_t* pos, size_t end, bool inItem, int depth, Visitor& visitor, std::string* err) const;
 
     std::string m_Path, m_Error;
     std::vector<unsigned char> m_Bytes;

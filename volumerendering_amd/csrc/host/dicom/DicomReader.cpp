@@ -143,9 +143,23 @@ std::shared_ptr<VolumeFileDcm> DicomReader::ReadVolumeFile(std::filesystem::path
             reader.m_Data.reserve(static_cast<size_t>(reader.m_Params.X) * reader.m_Params.Y * (isDir ? numberOfFiles : reader.m_Params.Z));
         }
         firstRun = false;
+        // every file must deliver exactly the pixels the first slice's geometry promises (the reference asserts
+        // vec.size() == X * Y * frames in ReadData, DicomReader.cpp:238,246): a slice with other Rows / Columns or a short
+        // PixelData element would leave the declared size larger than the data behind it
+        const size_t before = reader.m_Data.size();
         reader.ReadData(f);
+        const size_t expect = static_cast<size_t>(reader.m_Params.X) * reader.m_Params.Y * ((isDir && !hasSoloFile) ? 1 : reader.m_Params.Z);
+        if (reader.m_Data.size() - before != expect)
+            throw std::runtime_error("Pixel data of " + file.string() + " holds " + std::to_string(reader.m_Data.size() - before) +
+                                     " values, expected " + std::to_string(expect) + " (Rows x Columns x frames of the first slice)");
     }
-    if (isDir && !hasSoloFile) reader.m_Params.Z = static_cast<std::uint16_t>(numberOfFiles);
+    if (isDir && !hasSoloFile) {
+        if (numberOfFiles > 0xFFFFu) throw std::runtime_error("More than 65535 slices");
+        reader.m_Params.Z = static_cast<std::uint16_t>(numberOfFiles);
+    }
+    if (reader.m_Params.X == 0 || reader.m_Params.Y == 0 || reader.m_Params.Z == 0) throw std::runtime_error("Empty volume (Rows, Columns or frames is 0)");
+    if (reader.m_Data.size() != static_cast<size_t>(reader.m_Params.X) * reader.m_Params.Y * reader.m_Params.Z)
+        throw std::runtime_error("Pixel data does not match Rows x Columns x slices");
     VolumeFile::Size size{reader.m_Params.X, reader.m_Params.Y, reader.m_Params.Z};
     return std::make_shared<VolumeFileDcm>(name, size, reader.m_FileDataType, reader.m_Params, reader.m_Data);
 }

@@ -182,6 +182,7 @@ void vrh_volume_average_gradient(void* h, int k) { static_cast<VolumeHandle*>(h)
 const float* vrh_volume_data(void* h) { return static_cast<const float*>(static_cast<VolumeHandle*>(h)->v->GetVoidPtr()); }
 uint64_t vrh_volume_max_number(void* h) { return static_cast<VolumeHandle*>(h)->v->GetMaxNumber(); }
 uint64_t vrh_volume_data_range(void* h) { return static_cast<VolumeHandle*>(h)->v->GetDataRange(); }
+int vrh_volume_is_normalized(void* h) { return static_cast<VolumeHandle*>(h)->v->IsNormalized() ? 1 : 0; }
 int vrh_volume_index(void* h, int x, int y, int z) { return static_cast<VolumeHandle*>(h)->v->GetIndexFrom3D(x, y, z); }
 void vrh_volume_voxel(void* h, int x, int y, int z, float out[4])
 {
@@ -310,8 +311,7 @@ int vrh_app_start(void* a, int variant, void* v0, void* v1, void* v2, int tf_res
         case VR_VARIANT_TF_CALIB: scene = std::make_unique<TFCalibrationApp>(vol(v0), vol(v1), vol(v2)); break;
         default: return VR_ERR_INVALID_ARG;
         }
-        app->OnStart(std::move(scene));
-        return VR_OK;
+        return app->OnStart(std::move(scene));
     } catch (...) {
         return VR_ERR_INVALID_ARG;
     }

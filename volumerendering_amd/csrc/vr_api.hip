@@ -66,6 +66,8 @@ struct vr_ctx {
     // flight on different streams (the next ones fill the machine while the first one's long rays drain)
     unsigned long long* d_block_counts[kInFlight] = {};
     size_t block_counts_cap[kInFlight] = {};   // in blocks
+    hipEvent_t slot_done[kInFlight] = {};      // recorded behind the launch that last used the slot (any stream)
+    bool slot_used[kInFlight] = {};
     unsigned launch_seq = 0;
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
@@ -429,6 +431,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         dim3 block((unsigned)(dp ? 256 : 64 * wpb));
         dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 64 : 32) : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel
         const int cb = (int)(c->launch_seq++ % (unsigned)kInFlight);
+        // the slot's previous launch (kInFlight launches ago, possibly on another stream) must have finished before its
+        // record buffer is written again or re-allocated: this is what bounds the launches in flight to kInFlight
+        if (c->slot_used[cb]) VR_HIP(c, hipEventSynchronize(c->slot_done[cb]));
         if (grid.x > c->block_counts_cap[cb]) {
             if (c->d_block_counts[cb]) (void)hipFree(c->d_block_counts[cb]);
             c->d_block_counts[cb] = nullptr;
@@ -486,6 +491,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
+        VR_HIP(c, hipEventRecord(c->slot_done[cb], s));
+        c->slot_used[cb] = true;
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
         ++c->ring.head;
         c->cnt_blocks = (int)grid.x;
@@ -509,9 +516,9 @@ int fetch_counters(vr_ctx* c)
     if (!c->cnt_pending) return VR_OK;
     VR_HIP(c, hipSetDevice(c->device));
     if (c->cnt_blocks > 0) {
-        // the launch may have been enqueued on a stream of the caller's that no longer exists: wait for the device, then
-        // use the context's own stream
-        VR_HIP(c, hipDeviceSynchronize());
+        // the launch may have been enqueued on a stream of the caller's that no longer exists: wait for the event recorded
+        // behind it (owned by the context; other launches in flight are not waited for), then use the context's own stream
+        VR_HIP(c, hipEventSynchronize(c->slot_done[c->cnt_buf]));
         hipLaunchKernelGGL(sum_block_counts_kernel, dim3(1), dim3(256), 0, c->stream, c->d_block_counts[c->cnt_buf], c->cnt_blocks,
                            c->d_counters);
         VR_HIP(c, hipGetLastError());
@@ -549,7 +556,7 @@ int check_slot(vr_ctx* c, int slot, const char* who)
     if (slot < 0 || slot >= VR_MAX_VOLUMES) return fail(c, VR_ERR_INVALID_ARG, std::string(who) + ": bad slot");
     if (!c->vol[slot].data) return fail(c, VR_ERR_NOT_READY, std::string(who) + ": volume slot is empty");
     VR_HIP(c, hipSetDevice(c->device));
-    VR_HIP(c, hipStreamSynchronize(c->stream));
+    VR_HIP(c, hipDeviceSynchronize());  // asynchronous renders on the caller's streams may still read the slot
     return VR_OK;
 }
 
@@ -563,7 +570,7 @@ int upload_raw(vr_ctx* c, int slot, const T* raw, uint16_t nx, uint16_t ny, uint
     const size_t n = (size_t)nx * ny * nz;
     if (n > 0xFFFFFFFFull) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload_raw: more than 2^32 voxels");
     VR_HIP(c, hipSetDevice(c->device));
-    VR_HIP(c, hipStreamSynchronize(c->stream));
+    VR_HIP(c, hipDeviceSynchronize());  // asynchronous renders on the caller's streams may still read the slot
     const size_t bytes = n * sizeof(float4);
     if (c->vol[slot].data && c->vol_bytes[slot] != bytes) {
         (void)hipFree(const_cast<float4*>(c->vol[slot].data));
@@ -711,6 +718,8 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     for (int i = 0; i < kRing; ++i)
         if (!hip_ok(hipEventCreate(&c->ring.k0[i]), "hipEventCreate") || !hip_ok(hipEventCreate(&c->ring.k1[i]), "hipEventCreate"))
             return bail(VR_ERR_HIP);
+    for (int i = 0; i < kInFlight; ++i)
+        if (!hip_ok(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 3 * sizeof(unsigned long long), hipHostMallocDefault),
                 "hipHostMalloc"))
@@ -727,7 +736,8 @@ int vr_resize(vr_ctx* c, uint32_t width, uint32_t height)
     if (!c) return VR_ERR_INVALID_ARG;
     if (width == 0 || height == 0 || width > 32768 || height > 32768)
         return fail(c, VR_ERR_INVALID_ARG, "vr_resize: bad viewport size");
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();  // frames may be in flight on the caller's streams
     c->W = width;
     c->H = height;
     return alloc_frame(c);
@@ -737,7 +747,7 @@ void vr_destroy(vr_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();  // renders may be in flight on streams of the caller's
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
         if (c->vol[i].data) (void)hipFree(const_cast<float4*>(c->vol[i].data));
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
@@ -759,6 +769,8 @@ void vr_destroy(vr_ctx* c)
         if (c->ring.k0[i]) (void)hipEventDestroy(c->ring.k0[i]);
         if (c->ring.k1[i]) (void)hipEventDestroy(c->ring.k1[i]);
     }
+    for (auto e : c->slot_done)
+        if (e) (void)hipEventDestroy(e);
     if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
     if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);
     if (c->tm.ev_k1) (void)hipEventDestroy(c->tm.ev_k1);
@@ -778,7 +790,7 @@ static int volume_upload_common(vr_ctx* c, int slot, const void* src, bool src_i
     if (voxels > 0xFFFFFFFFull) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload: more than 2^32 voxels");
     size_t bytes = (size_t)voxels * sizeof(float4);
     VR_HIP(c, hipSetDevice(c->device));
-    VR_HIP(c, hipStreamSynchronize(c->stream));
+    VR_HIP(c, hipDeviceSynchronize());  // asynchronous renders on the caller's streams may still read the slot
     if (c->vol[slot].data && c->vol_bytes[slot] != bytes) {
         (void)hipFree(const_cast<float4*>(c->vol[slot].data));
         c->vol[slot] = DevVolume{};
@@ -817,7 +829,7 @@ static int tf_upload_one(vr_ctx* c, int slot, const float* table, uint32_t R, bo
     if (!table) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: table is NULL");
     if (R == 0 || R > (1u << 24)) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: bad resolution");
     VR_HIP(c, hipSetDevice(c->device));
-    VR_HIP(c, hipStreamSynchronize(c->stream));
+    VR_HIP(c, hipDeviceSynchronize());  // asynchronous renders on the caller's streams may still read the table
     if (is_color) {
         if (c->tf[slot].res_c != (int)R) {
             if (c->tf_color[slot]) (void)hipFree(c->tf_color[slot]);

@@ -38,6 +38,7 @@ def load() -> C.CDLL:
         "vrh_volume_normalize": (None, [vp, i32]), "vrh_volume_gradient": (None, [vp, i32]),
         "vrh_volume_average_gradient": (None, [vp, i32]), "vrh_volume_data": (vp, [vp]),
         "vrh_volume_max_number": (u64, [vp]), "vrh_volume_data_range": (u64, [vp]),
+        "vrh_volume_is_normalized": (i32, [vp]),
         "vrh_volume_index": (i32, [vp, i32, i32, i32]), "vrh_volume_voxel": (None, [vp, i32, i32, i32, vp]),
         "vrh_volume_size": (None, [vp, vp]), "vrh_volume_bbox": (None, [vp, vp]),
         "vrh_set_worker_threads": (None, [C.c_uint]),
@@ -174,6 +175,9 @@ class VolumeFile:
 
     def GetDataRange(self) -> int:
         return int(self.lib.vrh_volume_data_range(self.h))
+
+    def IsNormalized(self) -> bool:
+        return bool(self.lib.vrh_volume_is_normalized(self.h))
 
     def GetIndexFrom3D(self, x, y, z) -> int:
         return int(self.lib.vrh_volume_index(self.h, x, y, z))

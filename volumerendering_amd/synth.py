@@ -24,9 +24,10 @@ def xorshift32(x):
     return x
 
 
-def ct_phantom_raw(n, z0=0, z1=None):
+def ct_phantom_raw(n, z0=0, z1=None, air_noise=False):
     """Nested ellipsoids (air 0 / soft 1000-1100 / bone 2500-3000) + value noise +-40 from
-    xorshift32(0x5EED ^ voxel_index); 12-bit uint16.  Returns slices [z0,z1)."""
+    xorshift32(0x5EED ^ voxel_index); 12-bit uint16.  Returns slices [z0,z1).  air_noise: the air outside the
+    body carries the generator's noise as raw 0..80 (scanner-like: no voxel class is an exact constant)."""
     z1 = n if z1 is None else z1
     c = (n - 1) / 2.0
     h = n / 2.0
@@ -42,7 +43,7 @@ def ct_phantom_raw(n, z0=0, z1=None):
     val[inner] = 1040.0
     idx = ((zz.astype(np.uint64) * n + yy.astype(np.uint64)) * n + xx.astype(np.uint64)).astype(np.uint32)
     noise = (xorshift32(np.uint32(0x5EED) ^ idx) % np.uint32(81)).astype(np.int64) - 40
-    val = np.where(body, val + noise, 0.0)
+    val = np.where(body, val + noise, (noise + 40.0) if air_noise else 0.0)
     return np.clip(np.round(val), 0, 4095).astype(np.uint16)
 
 
@@ -80,6 +81,8 @@ def _hostlib():
     from . import host
     lib = host.load()
     lib.vrh_synth_ct_phantom.argtypes = [C.c_int, C.c_void_p]
+    lib.vrh_synth_ct_phantom_air.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    lib.vrh_synth_ct_phantom_air.restype = None
     lib.vrh_synth_sphere.argtypes = [C.c_int, C.c_void_p]
     lib.vrh_synth_mask.argtypes = [C.c_int, C.c_void_p]
     for f in (lib.vrh_synth_ct_phantom, lib.vrh_synth_sphere, lib.vrh_synth_mask):
@@ -87,9 +90,9 @@ def _hostlib():
     return lib
 
 
-def ct_phantom_raw_fast(n):
+def ct_phantom_raw_fast(n, air_noise=False):
     out = np.empty((n, n, n), dtype=np.uint16)
-    _hostlib().vrh_synth_ct_phantom(n, out.ctypes.data)
+    _hostlib().vrh_synth_ct_phantom_air(n, int(air_noise), out.ctypes.data)
     return out
 
 
