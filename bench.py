@@ -61,8 +61,26 @@ PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"]]
 
 
+PMC_EXTRA = [["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"], ["TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum"],
+             ["SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_INST_CYCLES_VMEM", "SQ_INSTS_SALU", "SQ_INSTS_LDS"],
+             ["SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT"]]
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPUs this process can really use: its affinity mask, cut down to the cgroup's CPU quota when one is set (the GPU
+    boxes expose every host CPU in the mask but grant a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
 
 
 # ------------------------------------------------------------------------------------------------ PMC child / passes
@@ -129,7 +147,7 @@ def oracle_legs(app, variant, vols, W, H, gpu_frame, gpu_samples, budget_s=25.0)
     import oracle_binding as ob
     from volumerendering_amd import workloads as wl
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     ub, volumes, tfs = wl.oracle_inputs(app, vols)
     uo = hr.Uniforms.from_buffer_copy(ub)
 
@@ -159,15 +177,20 @@ def oracle_legs(app, variant, vols, W, H, gpu_frame, gpu_samples, budget_s=25.0)
               "oracle_composited_samples": int(n_all), "tolerance": 1e-4}
     if stride == 1:
         parity["samples_equal"] = bool(n_all == gpu_samples)
-    # one thread: a grid sized for ~10 s from the all-core rate
-    rate1 = (n_all / dt_all) / cores if dt_all > 0 else 1.0
+    # one thread: a grid sized for ~10 s, from a one-thread calibration on 1 pixel of every 32 x 32
+    _, _, n_c1, dt_c1 = run(32, 1)
+    rate1 = n_c1 / dt_c1 if dt_c1 > 0 else 1.0
     s1 = stride
-    while s1 < 64 and (n_all * (stride / s1) ** 2) / max(rate1, 1.0) > 10.0:
+    while s1 < 32 and (n_all * (stride / s1) ** 2) / max(rate1, 1.0) > 10.0:
         s1 += 1
     p1, _, n_1, dt_1 = run(s1, 1)
-    base = {"value": round(n_all / dt_all / 1e9, 6), "unit": "Gsamples/s", "cores": cores, "kind": "port",
+    base = {"value": round(n_all / dt_all / 1e9, 6), "unit": "Gsamples/s", "cores": cores,
+            "cores_note": f"threads used = CPUs in this process's affinity mask ({len(os.sched_getaffinity(0))}), cut to the cgroup CPU quota when "
+                          "one is readable; speedup_over_one_thread says how many of them the box really grants",
+            "kind": "port",
             "implementation": "oracle/vr_oracle.c (scalar C restatement of the WGSL, pthread over pixels)",
             "sample": f"{parity['of_frame']} of the {W}x{H} frame ({pxy.shape[0]} rays, {n_all} composited samples, {dt_all:.2f} s)",
+            "speedup_over_one_thread": round((n_all / dt_all) / (n_1 / dt_1), 2) if dt_1 > 0 and n_1 else None,
             "one_thread": {"value": round(n_1 / dt_1 / 1e9, 6), "cores": 1,
                            "sample": f"one pixel of every {s1} x {s1} ({p1.shape[0]} rays, {n_1} composited samples, {dt_1:.2f} s)"}}
     return parity, base
@@ -185,6 +208,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--no-regimes", action="store_true", help="skip the air x TF regime table (C3)")
+    ap.add_argument("--pmc-extra", action="store_true", help="more counter passes (L1 / TA / wait states); all counters go into `pmc`")
     ap.add_argument("--flavour", type=int, default=0)
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
@@ -352,7 +376,7 @@ def main():
     pmc, pmc_note = ({}, "skipped")
     if rank == 0 and world == 1 and not multi and not args.no_live_pmc:
         t0 = time.time()
-        pmc, pmc_note = live_pmc(args)
+        pmc, pmc_note = live_pmc(args, PMC_PASSES + (PMC_EXTRA if args.pmc_extra else []))
         log(f"[bench] rocprofv3 counter passes: {time.time() - t0:.1f}s {pmc_note}")
     traffic = None
     traffic_source = None
@@ -433,6 +457,8 @@ def main():
         },
         "serial": serial, "overlapped": over, "roofline": roofline,
     }
+    if args.pmc_extra:
+        out["pmc"] = {"per": "march-kernel launch, mean of the profiled launches (one at a time), first launch dropped", **pmc}
 
     # ---- the regime table (C3): {exact-0 air, noisy air} x {default ramp, zero-prefix TF}, serial leg -------------
     if rank == 0 and not multi and args.workload == "C3" and not args.no_regimes and not args.vol_n:

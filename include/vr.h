@@ -54,7 +54,12 @@ typedef enum vr_variant {
      * opacityCT * pow(|g|, pow(5 s (1 - d) (1 - dst.a), 0.8)); slots as MULTI_CTRT, reads camera_pos.  The reference
      * compiles this module next to MultiCTRTApp.wgsl but never attaches it (MutliCTRTApp.cpp:112-119). */
     VR_VARIANT_ILLUSTRATIVE = 6,
-    VR_VARIANT_COUNT = 7
+    /* App/shaders/BasicVolLightApp.wgsl with the call the reference keeps commented out at :212 enabled:
+     * gradient = ComputeGradient(currentPosition, stepSize, textMain) (:239-253) -- central differences of six extra
+     * trilinear density samples at +-stepSize along the uvw axes, negated and normalised (zero length -> 0), instead of
+     * the pre-computed .rgb of the voxels.  Slots and light as LIGHT; only the density plane of the volume is read.  */
+    VR_VARIANT_LIGHT_INSHADER = 7,
+    VR_VARIANT_COUNT = 8
 } vr_variant;
 
 #define VR_MAX_VOLUMES 3

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvr_oracle.so")
 
-BASIC, LIGHT, VOLUME_MASK, THREE_FILES, MULTI_CTRT, TF_CALIB, ILLUSTRATIVE = range(7)
+BASIC, LIGHT, VOLUME_MASK, THREE_FILES, MULTI_CTRT, TF_CALIB, ILLUSTRATIVE, LIGHT_INSHADER = range(8)
 
 
 class Volume(C.Structure):

@@ -371,7 +371,7 @@ uint32_t vro_shade_pixel(int variant, const vro_uniforms* u, const vro_volume* v
 
     float step_size = u->step_size;
     float world_step[3] = { 0.0f, 0.0f, 0.0f };
-    if (variant == VRO_LIGHT) {
+    if (variant == VRO_LIGHT || variant == VRO_LIGHT_INSHADER) {
         /* CalculateWorldStep BEFORE the variable-step override: BasicVolLightApp.wgsl:184-185, 78-84 */
         world_step[0] = dir[0] * (step_size * 1.0f);
         world_step[1] = dir[1] * (step_size * 1.0f);
@@ -424,6 +424,36 @@ uint32_t vro_shade_pixel(int variant, const vro_uniforms* u, const vro_volume* v
                 float N[3], s[3];
                 normalize3(v, N);
                 shade(N, wc, lpos, ldif, lamb, 2.5f, 0.5f, s); /* BlinnPhong :137-147 */
+                rgb[0] *= s[0]; rgb[1] *= s[1]; rgb[2] *= s[2];
+                front_to_back_blend(rgb, opacity, dst);
+                ++blends;
+            }
+        } break;
+        case VRO_LIGHT_INSHADER: { /* BasicVolLightApp.wgsl:207-234 with :212 enabled: gradient = ComputeGradient(...) */
+            float v[4], rgb[3];
+            tex3_linear(&vols[0], p, v);
+            float density = v[3];
+            /* ComputeGradient(currentPosition, stepSize, textMain)  :239-253; dirs[k] * step = (step,0,0) ... */
+            float r[3], g[3];
+            for (int a = 0; a < 3; ++a) {
+                float dv[3] = { ((a == 0) ? 1.0f : 0.0f) * step_size, ((a == 1) ? 1.0f : 0.0f) * step_size,
+                                ((a == 2) ? 1.0f : 0.0f) * step_size };
+                float pp[3] = { p[0] + dv[0], p[1] + dv[1], p[2] + dv[2] };
+                float pm[3] = { p[0] - dv[0], p[1] - dv[1], p[2] - dv[2] };
+                float sp[4], sm[4];
+                tex3_linear(&vols[0], pp, sp);
+                tex3_linear(&vols[0], pm, sm);
+                r[a] = sp[3] - sm[3];
+            }
+            float l = length3(r);
+            if (l == 0.0f) { g[0] = g[1] = g[2] = 0.0f; }
+            else { g[0] = (-r[0]) / l; g[1] = (-r[1]) / l; g[2] = (-r[2]) / l; }
+            float opacity = tf_opacity(&tfs[0], density);
+            tf_color(&tfs[0], density, rgb);
+            if (in_sample_coords(u, p) && dst[3] < 1.0f) {
+                float N[3], s[3];
+                normalize3(g, N); /* normalize(vec3(0)) = NaN -> max(NaN, 0) = 0: ambient only */
+                shade(N, wc, lpos, ldif, lamb, 2.5f, 0.5f, s);
                 rgb[0] *= s[0]; rgb[1] *= s[1]; rgb[2] *= s[2];
                 front_to_back_blend(rgb, opacity, dst);
                 ++blends;

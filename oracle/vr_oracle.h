@@ -33,7 +33,8 @@ typedef struct vro_volume { const float* vec4; int32_t nx, ny, nz; } vro_volume;
 typedef struct vro_tf { const float* opacity; const float* color_rgba; int32_t res; int32_t res_color; } vro_tf; /* res = opacity table */
 
 enum { VRO_BASIC = 0, VRO_LIGHT = 1, VRO_VOLUME_MASK = 2, VRO_THREE_FILES = 3, VRO_MULTI_CTRT = 4, VRO_TF_CALIB = 5,
-       VRO_ILLUSTRATIVE = 6 /* MutliCTRTIllustrative.wgsl (compiled but never attached by the reference) */ };
+       VRO_ILLUSTRATIVE = 6, /* MutliCTRTIllustrative.wgsl (compiled but never attached by the reference) */
+       VRO_LIGHT_INSHADER = 7 /* BasicVolLightApp.wgsl with line 212 enabled: gradient = ComputeGradient(...) :239-253 */ };
 
 /* Ray set-up for one pixel (restates rayCoords.wgsl + the vertex stage + rasteriser).
  * Returns 1 when the pixel has a fragment; start/end are uvw, world0 the world-space entry. */

@@ -14,7 +14,7 @@ f32 = np.float32
 
 def scene_inputs(variant, n):
     ct = host.VolumeFile.from_raw(synth.ct_phantom_raw(n))
-    if variant in (capi.BASIC, capi.LIGHT):
+    if variant in (capi.BASIC, capi.LIGHT, capi.LIGHT_INSHADER):
         return [ct]
     dose = host.VolumeFile.from_raw(synth.dose_raw(24, 20, 12))
     mask = host.VolumeFile.from_vec4(synth.mask_vec4(n), 1)
@@ -29,7 +29,7 @@ def scene_inputs(variant, n):
     return [ct, mask, host.VolumeFile.from_vec4(unfilled, 1)]
 
 
-@pytest.mark.parametrize("variant", range(7))
+@pytest.mark.parametrize("variant", range(8))
 def test_scene_through_host_surface(variant):
     W, H, n = 112, 72, 20
     vols = scene_inputs(variant, n)

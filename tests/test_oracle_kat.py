@@ -242,3 +242,40 @@ def test_reproducible_pow_is_a_correctly_rounded_pow():
     assert ob.pow_rep(0.0, 0.8) == 0.0 and ob.pow_rep(5.0, 0.0) == 1.0 and ob.pow_rep(1.0, 123.0) == 1.0
     assert math.isnan(ob.pow_rep(0.0, 0.0)) and math.isnan(ob.pow_rep(-1.0, 2.0)) and math.isnan(ob.pow_rep(float("nan"), 1.0))
     assert ob.pow_rep(float("inf"), -1.0) == 0.0 and ob.pow_rep(10.0, 60.0) == float("inf") and ob.pow_rep(10.0, -60.0) == 0.0
+
+
+def test_in_shader_gradient_known_answers():
+    """ComputeGradient (BasicVolLightApp.wgsl:239-253, the call commented out at :212) as a variant of the lit shader.
+    (1) constant medium: every central difference is exactly 0 -> the function returns vec3(0) -> normalize gives NaN ->
+        max(NaN, 0) = 0: ambient only, bit-identical to the lit shader on voxels whose .rgb is 0;
+    (2) a field linear in x, constant in y and z, sampled away from the volume's edges: the linear filter reproduces
+        a value that does not depend on y / z, so r.y = r.z = 0 exactly and r.x > 0 -> the function returns (-1, -0, -0):
+        bit-identical to the lit shader on voxels whose .rgb is (-1, 0, 0)."""
+    n, res = 16, 64
+    tf = const_tf(res, 0.03, (0.9, 0.5, 0.2))
+    u = hr.make_uniforms(W, H, steps_count=40, step_size=1 / 16)
+    v0 = const_volume(n, 0.6)
+    a, na, _ = ob.render(ob.LIGHT_INSHADER, u, [v0], [tf], W, H)
+    b, nb, _ = ob.render(ob.LIGHT, u, [v0], [tf], W, H)
+    assert na == nb > 0 and np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # ambient only: rgb = tf colour * (ambient * 0.5) accumulated; ratios of the channels are those of the colour
+    cov = a[..., 3] > 0
+    assert np.allclose(a[cov][:, 1] / a[cov][:, 0], 0.5 / 0.9, rtol=1e-5)
+
+    ramp = np.zeros((n, n, n, 4), dtype=f32)
+    ramp[..., 3] = (np.arange(n, dtype=f32) / f32(n - 1))[None, None, :]
+    lit = ramp.copy()
+    lit[..., 0] = -1.0
+    o = (np.arange(res, dtype=f32) / f32(res - 1) * f32(0.05)).astype(f32)
+    tf2 = (o, hr.default_color_tf(res))
+    u2 = hr.make_uniforms(W, H, steps_count=40, step_size=1 / 16, clip_x=(0.2, 0.2), clip_y=(0.2, 0.2), clip_z=(0.2, 0.2))
+    a, na, _ = ob.render(ob.LIGHT_INSHADER, u2, [ramp], [tf2], W, H)
+    b, nb, _ = ob.render(ob.LIGHT, u2, [lit], [tf2], W, H)
+    assert na == nb > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # and the gradient really is used: with the light on the +x side (N = -x faces away) only ambient remains,
+    # with the light on the -x side the frame is brighter
+    def with_light(x):
+        uu = hr.make_uniforms(W, H, steps_count=40, step_size=1 / 16, clip_x=(0.2, 0.2), clip_y=(0.2, 0.2), clip_z=(0.2, 0.2))
+        uu.light_pos[0], uu.light_pos[1], uu.light_pos[2] = x, 0.0, 0.0
+        return ob.render(ob.LIGHT_INSHADER, uu, [ramp], [tf2], W, H)[0]
+    assert with_light(-5.0)[..., 0].sum() > 1.5 * with_light(5.0)[..., 0].sum()

@@ -44,7 +44,7 @@ def check(ctx, variant, u, vols, tfs, W, H):
     return frag, n
 
 
-@pytest.mark.parametrize("variant", range(7))
+@pytest.mark.parametrize("variant", range(8))
 def test_every_variant_bit_exact(ctx, variant):
     W, H = 96, 80
     vols, tfs = vt.scene(variant, n=24)
@@ -54,7 +54,7 @@ def test_every_variant_bit_exact(ctx, variant):
     assert n > 0 and np.nanmax(frag[..., 3]) > 0
 
 
-@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.MULTI_CTRT])
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.MULTI_CTRT, capi.LIGHT_INSHADER])
 def test_thin_tf_no_termination(ctx, variant):
     W, H = 64, 48
     vols, tfs = vt.scene(variant, n=16, thin=True)
@@ -70,7 +70,7 @@ def test_debug_modes(ctx, mode):
     check(ctx, capi.LIGHT, u, vols, tfs, W, H)
 
 
-@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.VOLUME_MASK])
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.VOLUME_MASK, capi.LIGHT_INSHADER])
 def test_clips_variable_step_and_jitter(ctx, variant):
     W, H = 64, 48
     vols, tfs = vt.scene(variant, n=16)
@@ -180,7 +180,7 @@ def zero_prefix_tf(res, zeros, top=0.3):
     return o, hr.default_color_tf(res)
 
 
-@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.VOLUME_MASK])
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.VOLUME_MASK, capi.LIGHT_INSHADER])
 @pytest.mark.parametrize("zeros", [0, 1, 2, 9, 17, 40, 64])
 def test_empty_space_skipping_is_exact(ctx, variant, zeros):
     """Skipped samples are exactly the identity: flavour 0 (skipping) == flavour 1 (plain) == oracle, bit for bit,
@@ -231,7 +231,7 @@ def test_skipping_with_hostile_values(ctx):
     step, count = hr.stepping_params(n, n, n)
     u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
     tf = zero_prefix_tf(32, 3)
-    for variant in (capi.BASIC, capi.LIGHT):
+    for variant in (capi.BASIC, capi.LIGHT, capi.LIGHT_INSHADER):
         ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
         for flavour in (0, 1, 5, 6, 8, 9, 11):  # every loop form and lanes-per-ray layout
             ctx.set_kernel_flavour(flavour)
@@ -376,7 +376,9 @@ def test_exact_leaping_flavour(ctx, flavour):
                 kw.update(cam)
                 kw.update(extra)
                 u = hr.make_uniforms(W, H, **kw)
-                for variant in (capi.BASIC, capi.LIGHT, capi.THREE_FILES):
+                for variant in (capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.LIGHT_INSHADER):
+                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6):
+                        continue  # one-lane kernel only: the other flavours resolve to 6
                     vols = [v] if variant != capi.THREE_FILES else [v, vt.dose_volume()]
                     tfs = [tf] if variant != capi.THREE_FILES else [tf, vt.scene(capi.THREE_FILES, n=8)[1][1]]
                     check(ctx, variant, u, vols, tfs, W, H)
@@ -389,7 +391,7 @@ def test_exact_leaping_flavour(ctx, flavour):
 
 
 @pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11])
-@pytest.mark.parametrize("variant", range(7))
+@pytest.mark.parametrize("variant", range(8))
 def test_every_variant_every_layout(ctx, variant, flavour):
     """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
     forced here for every shader, with clips / variable step / jitter and a ragged viewport."""

@@ -45,7 +45,7 @@ def scene(variant, n=16, tf_res=64, thin=False):
     tf1 = (o1, c1)
     if variant == capi.BASIC:
         return [make_volume("phantom", n)], [tf0]
-    if variant == capi.LIGHT:
+    if variant in (capi.LIGHT, capi.LIGHT_INSHADER):
         return [make_volume("phantom", n, gradient=True)], [tf0]
     if variant == capi.VOLUME_MASK:
         return [hr.mask_vec4(n), dose_volume(), make_volume("phantom", n, norm01=True, grad_first=True)], [tf0, tf1]

@@ -20,8 +20,8 @@ VR_ERR_NOT_READY = -3
 VR_ERR_UNSUPPORTED = -4
 VR_ERR_OOM = -5
 
-BASIC, LIGHT, VOLUME_MASK, THREE_FILES, MULTI_CTRT, TF_CALIB, ILLUSTRATIVE = range(7)
-VARIANT_NAMES = ["BASIC", "LIGHT", "VOLUME_MASK", "THREE_FILES", "MULTI_CTRT", "TF_CALIB", "ILLUSTRATIVE"]
+BASIC, LIGHT, VOLUME_MASK, THREE_FILES, MULTI_CTRT, TF_CALIB, ILLUSTRATIVE, LIGHT_INSHADER = range(8)
+VARIANT_NAMES = ["BASIC", "LIGHT", "VOLUME_MASK", "THREE_FILES", "MULTI_CTRT", "TF_CALIB", "ILLUSTRATIVE", "LIGHT_INSHADER"]
 TILE = 64
 
 # every symbol include/vr.h declares (tests check that the library exports each of them)

@@ -86,13 +86,17 @@ public:
     explicit BasicVolLightApp(VolumePtr ct, int tfResolution = 4096) : p_Ct(std::move(ct)), m_TfRes(tfResolution) {}
     void OnStart(vr_ctx* ctx) override;
     void OnUpdate() override;
-    int Variant() const override { return VR_VARIANT_LIGHT; }
+    int Variant() const override { return m_InShaderGradient ? VR_VARIANT_LIGHT_INSHADER : VR_VARIANT_LIGHT; }
+    // renders with the shader's own ComputeGradient (BasicVolLightApp.wgsl:239-253), the call the reference keeps
+    // commented out at :212, instead of the voxels' pre-computed .rgb
+    void SetInShaderGradient(bool on) { m_InShaderGradient = on; }
     const Light* GetLight() const override { return &m_Light1; }
     std::unique_ptr<OpacityTF> p_OpacityTf;
     std::unique_ptr<ColorTF> p_ColorTf;
 private:
     VolumePtr p_Ct;
     int m_TfRes;
+    bool m_InShaderGradient = false;
     Light m_Light1{vrm::vec4(0.0f, 5.0f, 0.0f, 1.0f), vrm::vec4(0.1f), vrm::vec4(1.0f)};
 };
 

@@ -299,6 +299,12 @@ int vrh_app_start(void* a, int variant, void* v0, void* v1, void* v2, int tf_res
         switch (variant) {
         case VR_VARIANT_BASIC: scene = std::make_unique<BasicVolumeApp>(vol(v0), tf_res > 0 ? tf_res : 256); break;
         case VR_VARIANT_LIGHT: scene = std::make_unique<BasicVolLightApp>(vol(v0), tf_res > 0 ? tf_res : 4096); break;
+        case VR_VARIANT_LIGHT_INSHADER: {
+            auto m = std::make_unique<BasicVolLightApp>(vol(v0), tf_res > 0 ? tf_res : 4096);
+            m->SetInShaderGradient(true);
+            scene = std::move(m);
+            break;
+        }
         case VR_VARIANT_VOLUME_MASK: scene = std::make_unique<VolumeMaskApp>(vol(v0), vol(v1), vol(v2)); break;
         case VR_VARIANT_THREE_FILES: scene = std::make_unique<ThreeFilesApp>(vol(v0), vol(v1), vol(v2)); break;
         case VR_VARIANT_MULTI_CTRT: scene = std::make_unique<MultiCTRTApp>(vol(v0), vol(v1)); break;

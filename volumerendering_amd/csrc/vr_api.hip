@@ -128,7 +128,8 @@ void variant_needs(int variant, int* nvol, int* ntf)
 {
     switch (variant) {
     case VR_VARIANT_BASIC:
-    case VR_VARIANT_LIGHT: *nvol = 1; *ntf = 1; break;
+    case VR_VARIANT_LIGHT:
+    case VR_VARIANT_LIGHT_INSHADER: *nvol = 1; *ntf = 1; break;
     case VR_VARIANT_VOLUME_MASK: *nvol = 3; *ntf = 2; break;
     case VR_VARIANT_THREE_FILES: *nvol = 2; *ntf = 2; break;  // the mask (slot 2) is bound but never sampled
     case VR_VARIANT_MULTI_CTRT: *nvol = 2; *ntf = 2; break;
@@ -154,7 +155,7 @@ int alloc_frame(vr_ctx* c)
 template <int V>
 void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchParams& P)
 {
-    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
+    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK || V == V_LIGHT_INSHADER);
 #define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L>), grid, block, 0, s, P)
     if constexpr (kCanSkip) {
         if (P.brick_dist) {
@@ -323,7 +324,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     // zero-opacity sample is provably the identity (finite colour table and light), and unless flavour 1 asks
     // for the plain kernel
     const bool skip_variant = variant == VR_VARIANT_BASIC || variant == VR_VARIANT_LIGHT ||
-                              variant == VR_VARIANT_THREE_FILES || variant == VR_VARIANT_VOLUME_MASK;
+                              variant == VR_VARIANT_THREE_FILES || variant == VR_VARIANT_VOLUME_MASK ||
+                              variant == VR_VARIANT_LIGHT_INSHADER;
     const int sv = (variant == VR_VARIANT_VOLUME_MASK) ? 2 : 0;  // the volume whose density drives tf[0]'s opacity
     int fl = c->flavour == 0 ? c->default_flavour : c->flavour;
     if (fl == 0) {
@@ -338,6 +340,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     }
     // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
     if (variant == VR_VARIANT_ILLUSTRATIVE && (fl == 7 || fl == 8 || fl == 10 || fl == 11)) fl = 6;
+    // the in-shader gradient variant (seven density fetches per sample) exists as the one-lane kernel only
+    if (variant == VR_VARIANT_LIGHT_INSHADER && fl != 1 && fl != 4 && fl != 5) fl = 6;
     c->last_flavour = fl;
     bool can_skip = skip_variant && fl != 1 && fl != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
@@ -487,6 +491,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, P); break;
         case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, P); break;
         case VR_VARIANT_ILLUSTRATIVE: launch_variant<V_ILLUSTRATIVE>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_LIGHT_INSHADER: launch_variant<V_LIGHT_INSHADER>(off32, leap_mode, grid, block, s, P); break;
         default: launch_variant<V_TF_CALIB>(off32, leap_mode, grid, block, s, P); break;
         }
         VR_HIP(c, hipGetLastError());

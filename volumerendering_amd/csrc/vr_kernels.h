@@ -25,7 +25,7 @@
 namespace vr {
 
 enum Variant : int { V_BASIC = 0, V_LIGHT = 1, V_VOLUME_MASK = 2, V_THREE_FILES = 3, V_MULTI_CTRT = 4, V_TF_CALIB = 5,
-                     V_ILLUSTRATIVE = 6 };
+                     V_ILLUSTRATIVE = 6, V_LIGHT_INSHADER = 7 };
 
 struct f3 {
     float x, y, z;
@@ -516,7 +516,7 @@ template <int V>
 __device__ __forceinline__ bool can_blend(float a)  // the shader's opacity cut-off
 {
     if constexpr (V == V_BASIC || V == V_MULTI_CTRT || V == V_TF_CALIB || V == V_ILLUSTRATIVE)
-        return a <= 0.95f;
+        return a <= 0.95f;  // (V_LIGHT_INSHADER is BasicVolLightApp.wgsl: dst.a < 1.0, :220)
     else
         return a < 1.0f;
 }
@@ -527,9 +527,11 @@ struct Src {
     f3 rgb;
     float a;
 };
-// (start = the ray's first position and dst_a = the opacity accumulated so far are read by the illustrative shader only)
+// (start = the ray's first position and dst_a = the opacity accumulated so far are read by the illustrative shader only,
+// ss = the ray's step size after the variable-step override by the in-shader gradient only)
 template <int V, bool OFF32>
-__device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 start = f3{0.0f, 0.0f, 0.0f}, float dst_a = 0.0f)
+__device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 start = f3{0.0f, 0.0f, 0.0f}, float dst_a = 0.0f,
+                                          float ss = 0.0f)
 {
     Src o;
     if constexpr (V == V_BASIC) {
@@ -541,6 +543,24 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
         float4 v = tex3_rgba<OFF32>(P.vol[0], p);
         TfSample t = tf_lookup(P.tf[0], v.w);
         f3 N = normalize3(mk3(v.x, v.y, v.z));
+        f3 s = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
+                     mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
+                     mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
+        o.rgb = mk3(t.rgb.x * s.x, t.rgb.y * s.y, t.rgb.z * s.z);
+        o.a = t.opacity;
+    } else if constexpr (V == V_LIGHT_INSHADER) {
+        // BasicVolLightApp.wgsl:209-222 with :212 enabled; ComputeGradient :239-253.  dirs[k] * step = (step, 0, 0) ...:
+        // the products with 0 and the additions of the resulting zeros are kept (they are the shader's operations)
+        float density = tex3_a<OFF32>(P.vol[0], p);
+        TfSample t = tf_lookup(P.tf[0], density);
+        const float d1 = 1.0f * ss, d0 = 0.0f * ss;
+        const float rx = tex3_a<OFF32>(P.vol[0], mk3(p.x + d1, p.y + d0, p.z + d0)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d1, p.y - d0, p.z - d0));
+        const float ry = tex3_a<OFF32>(P.vol[0], mk3(p.x + d0, p.y + d1, p.z + d0)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d0, p.y - d1, p.z - d0));
+        const float rz = tex3_a<OFF32>(P.vol[0], mk3(p.x + d0, p.y + d0, p.z + d1)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d0, p.y - d0, p.z - d1));
+        const float l = length3(mk3(rx, ry, rz));
+        f3 g = mk3(0.0f, 0.0f, 0.0f);
+        if (l != 0.0f) g = mk3((-rx) / l, (-ry) / l, (-rz) / l);  // (NaN length: the division gives NaN, as in the shader)
+        f3 N = normalize3(g);  // normalize(vec3(0)) = NaN -> max(NaN, 0) = 0: ambient only
         f3 s = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
                      mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
                      mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
@@ -620,7 +640,7 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     return o;
 }
 template <int V, bool OFF32>
-__device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst, f3 start)
+__device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst, f3 start, float ss)
 {
     if constexpr (V == V_LIGHT) {
         // sample_src<V_LIGHT> + blend, written on (x, y) / (r, g) register pairs from the interpolation to the blend so
@@ -658,7 +678,7 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         dst.z = om * src_b + dst.z;
         dst.w = om * opacity + dst.w;
     } else {
-        const Src s = sample_src<V, OFF32>(P, p, w, start, dst.w);
+        const Src s = sample_src<V, OFF32>(P, p, w, start, dst.w, ss);
         blend(s.rgb, s.a, dst);
     }
 }
@@ -881,7 +901,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
             } else {
                 float step_size = P.step_size;
                 f3 wstep = mk3(0.0f, 0.0f, 0.0f);
-                if constexpr (V == V_LIGHT) {  // CalculateWorldStep before the override
+                if constexpr (V == V_LIGHT || V == V_LIGHT_INSHADER) {  // CalculateWorldStep before the override
                     wstep = mk3(dir.x * (step_size * 1.0f), dir.y * (step_size * 1.0f), dir.z * (step_size * 0.5f));
                     wstep.z = wstep.z * (-1.0f);
                 }
@@ -1052,7 +1072,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                                     blend(t.rgb, t.opacity, dst);
                                 }
                             } else {
-                                sample_and_blend<V, OFF32>(P, p, w, dst, ray.start);
+                                sample_and_blend<V, OFF32>(P, p, w, dst, ray.start, step_size);
                             }
                             ++fetched;
                             ++blends;
