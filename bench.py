@@ -93,6 +93,7 @@ def pmc_child(args):
         wl.build_scene(app, args.workload, args.tf, args.air, args.vol_n, quiet=True)
         if args.flavour:
             app.context().set_kernel_flavour(args.flavour)
+        app.context().set_volume_layout(args.layout)
         for _ in range(4):
             app.OnRender()
 
@@ -112,7 +113,7 @@ def live_pmc(args, passes=PMC_PASSES, timeout_s=150):
         d = os.path.join(tmp, f"pass{i}")
         cmd = [prof, "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload, "--tf", args.tf, "--air", args.air,
-               "--flavour", str(args.flavour), "--vol-n", str(args.vol_n)]
+               "--flavour", str(args.flavour), "--vol-n", str(args.vol_n), "--layout", str(args.layout)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
         except Exception as e:  # noqa: BLE001
@@ -210,6 +211,8 @@ def main():
     ap.add_argument("--no-regimes", action="store_true", help="skip the air x TF regime table (C3)")
     ap.add_argument("--pmc-extra", action="store_true", help="more counter passes (L1 / TA / wait states); all counters go into `pmc`")
     ap.add_argument("--flavour", type=int, default=0)
+    ap.add_argument("--layout", type=int, default=0, choices=[0, 1],
+                    help="vr_set_volume_layout: 0 density plane + gradients on the fly where verified, 1 the reference's vec4 voxels only")
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="frames in flight in the overlapped leg (1 = that leg is a second serial leg)")
@@ -258,6 +261,7 @@ def main():
     ctx = app.context()
     if args.flavour:
         ctx.set_kernel_flavour(args.flavour)
+    ctx.set_volume_layout(args.layout)
     if args.exp_mode or args.exp_steps >= 0:  # experiments only: not the BASELINE workload any more
         app.set_params(fragment_mode=args.exp_mode, steps_count=args.exp_steps)
         app.OnUpdate()
@@ -353,6 +357,7 @@ def main():
     else:
         total_samples, covered, total_fetched = my_samples, my_covered, my_fetched
     ran = ctx.last_kernel_flavour()
+    layout_flags = ctx.volume_layout(2 if vname == "VOLUME_MASK" else 0)
 
     def leg(dt, kt, nbuf):
         ms = dt / args.steps * 1e3
@@ -454,6 +459,8 @@ def main():
             "partition": part, "value_is": f"overlapped leg ({over['frames_in_flight']} frames in flight); one frame at a time in `serial`",
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
             "covered_pixels": covered, "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
+            "volume_layout": ("density plane for .a fetches" + (", corner gradients derived on the fly" if layout_flags & 4 else ""))
+                             if args.layout == 0 else "reference vec4 voxels only",
         },
         "serial": serial, "overlapped": over, "roofline": roofline,
     }
@@ -479,6 +486,7 @@ def main():
                 ctx = app.context()
                 if args.flavour:
                     ctx.set_kernel_flavour(args.flavour)
+                ctx.set_volume_layout(args.layout)
             current = (air, tf)
 
         regimes = []

@@ -253,6 +253,17 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *      the default uses for small launches)                                                                  */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 
+/* Volume layout in HBM (A/B measurements; frames and counts are bit-identical either way).
+ *   0  auto (default): next to the reference's vec4 voxels every slot keeps a scalar f32 density plane (4 B / voxel);
+ *      fetches that consume .a alone (BasicVolumeApp.wgsl:171 and the density / dose fetches of the other shaders) read
+ *      it, and the lit shader derives the eight corner gradients from it on the fly when the slot's .rgb is verified, at
+ *      upload, to be VolumeFile::PreComputeGradient(false) of its .a bit for bit (VolumeFile.cpp:196-257)
+ *   1  the reference's RGBA32F voxels only (16 B / voxel; what round 1 measured)
+ * vr_volume_layout: *flags bit 0 = density plane present, bit 1 = .rgb verified as the central difference of .a,
+ * bit 2 = the last render derived its gradients on the fly.                                                    */
+int vr_set_volume_layout(vr_ctx* ctx, int mode);
+int vr_volume_layout(vr_ctx* ctx, int slot, int* flags);
+
 /* The flavour the last render actually ran (what 0 resolved to for that launch), or a negative vr_status. */
 int vr_last_kernel_flavour(vr_ctx* ctx);
 

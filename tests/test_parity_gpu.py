@@ -514,3 +514,87 @@ def test_two_frames_in_flight_on_two_streams(ctx):
         for i in range(2):
             hip.hipStreamDestroy(streams[i])
             hip.hipFree(bufs[i])
+
+
+# ---- volume layout in HBM: density plane + gradients on the fly (vr_set_volume_layout) --------------------------------
+def test_density_plane_and_on_the_fly_gradients_are_exact(ctx):
+    """Layout 0 (density plane for .a fetches; the lit shader derives the corner gradients from it when the voxels' .rgb is
+    verified to be PreComputeGradient(false) of .a) and layout 1 (the reference's vec4 voxels only) give the same bits and
+    counts as the oracle, for every shader; the verification recognises derived and foreign gradients."""
+    W, H = 88, 60
+    step, count = hr.stepping_params(24, 24, 24)
+    try:
+        for variant in range(8):
+            vols, tfs = vt.scene(variant, n=24)
+            for kw in (dict(), dict(yaw=2.4, pitch=-0.7, distance=0.9), dict(clip_x=(0.1, 0.3), toggles=(1, 1, 0, 0))):
+                args = dict(steps_count=count, step_size=step)
+                args.update(kw)
+                u = hr.make_uniforms(W, H, **args)
+                for mode in (0, 1):
+                    ctx.set_volume_layout(mode)
+                    for fl in (0, 6, 1):
+                        ctx.set_kernel_flavour(fl)
+                        check(ctx, variant, u, vols, tfs, W, H)
+                        if variant == capi.LIGHT:
+                            flags = ctx.volume_layout(0)
+                            assert flags & 1 and flags & 2            # plane present, gradient recognised as derived
+                            assert bool(flags & 4) == (mode == 0 and ctx.last_kernel_flavour() in (1, 4, 5, 6, 9))
+    finally:
+        ctx.set_volume_layout(0)
+        ctx.set_kernel_flavour(0)
+
+
+def test_gradient_verification_and_boundary_cells(ctx):
+    W, H = 72, 56
+    ctx.set_kernel_flavour(6)
+    try:
+        # tiny and ragged grids: cells touch the faces everywhere (n < 4: the generic corner path only)
+        for shape in [(3, 3, 3), (2, 5, 9), (4, 4, 4), (5, 4, 7), (1, 8, 8), (9, 1, 6)]:
+            raw = hr.ct_phantom_raw(16)[: shape[0], : shape[1], : shape[2]]
+            v = ob.precompute_gradient(ob.normalize_data(hr.raw_to_vec4(raw)))
+            tf = (hr.default_opacity_tf(32), hr.default_color_tf(32))
+            for cam in (dict(), dict(yaw=1.9, pitch=0.8, distance=0.75)):
+                u = hr.make_uniforms(W, H, steps_count=45, step_size=1 / 24, **cam)
+                check(ctx, capi.LIGHT, u, [v], [tf], W, H)
+                assert ctx.volume_layout(0) & 6 == 6
+        # constant medium: interior gradients are -0.0 (the bits PreComputeGradient produces), recognised and reproduced
+        c = ob.precompute_gradient(np.full((12, 12, 12, 4), 0.4, dtype=f32))
+        assert np.signbit(c[5, 5, 5, 0]) and c[5, 5, 5, 0] == 0
+        u = hr.make_uniforms(W, H, steps_count=30, step_size=1 / 12)
+        check(ctx, capi.LIGHT, u, [c], [(hr.default_opacity_tf(16), hr.default_color_tf(16))], W, H)
+        assert ctx.volume_layout(0) & 6 == 6
+        # foreign gradients: normalised to [0,1], +0.0 instead of -0.0, one voxel off by an ulp, a NaN -> vec4 fetch
+        n = 16
+        base = ob.precompute_gradient(ob.normalize_data(hr.raw_to_vec4(hr.ct_phantom_raw(n))))
+        for spoil in ("norm01", "pluszero", "ulp", "nan"):
+            v = base.copy()
+            if spoil == "norm01":
+                v = ob.precompute_gradient(ob.normalize_data(hr.raw_to_vec4(hr.ct_phantom_raw(n))), True)
+            elif spoil == "pluszero":
+                z = (v[..., :3] == 0) & np.signbit(v[..., :3])
+                assert z.any()
+                v[..., :3][z] = 0.0
+            elif spoil == "ulp":
+                v[7, 8, 9, 1] = np.nextafter(v[7, 8, 9, 1], f32(1))
+            else:
+                v[3, 3, 3, 2] = np.nan
+            u = hr.make_uniforms(W, H, steps_count=27, step_size=1 / 16)
+            frag, _, ns = vt.gpu_render(ctx, capi.LIGHT, u, [v], [(hr.default_opacity_tf(32), hr.default_color_tf(32))])
+            ref, n_ref, _ = ob.render(capi.LIGHT, u, [v], [(hr.default_opacity_tf(32), hr.default_color_tf(32))], W, H, nthreads=8)
+            assert same(frag, ref) and ns == n_ref, spoil
+            assert ctx.volume_layout(0) & 7 == 1, spoil   # plane present, gradient NOT derived, nothing derived on the fly
+        # in-place preparation on the device keeps the plane and the verdict current
+        ctx.volume_upload_raw(0, hr.ct_phantom_raw(n))
+        assert ctx.volume_layout(0) & 2 == 0              # raw value broadcast to all lanes: not a gradient
+        ctx.volume_normalize(0)
+        ctx.volume_precompute_gradient(0)
+        assert ctx.volume_layout(0) & 2
+        ctx.tf_upload(0, hr.default_opacity_tf(32), hr.default_color_tf(32))
+        u = hr.make_uniforms(W, H, steps_count=27, step_size=1 / 16)
+        ctx.set_uniforms(vt.to_capi_uniforms(u))
+        ctx.render(capi.LIGHT)
+        frag, _, ns = ctx.download()
+        ref, n_ref, _ = ob.render(capi.LIGHT, u, [base], [(hr.default_opacity_tf(32), hr.default_color_tf(32))], W, H, nthreads=8)
+        assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref and ctx.volume_layout(0) & 4
+    finally:
+        ctx.set_kernel_flavour(0)

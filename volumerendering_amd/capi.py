@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
+    "vr_set_volume_layout", "vr_volume_layout",
 ]
 
 
@@ -104,6 +105,8 @@ def load() -> C.CDLL:
     lib.vr_last_block_trace.argtypes = [vp, C.c_void_p, C.c_int]
     lib.vr_set_kernel_flavour.argtypes = [vp, i32]
     lib.vr_last_kernel_flavour.argtypes = [vp]
+    lib.vr_set_volume_layout.argtypes = [vp, i32]
+    lib.vr_volume_layout.argtypes = [vp, i32, C.POINTER(C.c_int)]
     _lib = lib
     return lib
 
@@ -270,6 +273,16 @@ class Context:
 
     def last_kernel_flavour(self) -> int:
         return self._chk(self.lib.vr_last_kernel_flavour(self.h))
+
+    def set_volume_layout(self, mode: int):
+        """0 auto (density plane + on-the-fly gradients where verified), 1 the reference's vec4 voxels only."""
+        self._chk(self.lib.vr_set_volume_layout(self.h, mode))
+
+    def volume_layout(self, slot: int) -> int:
+        """bit 0 density plane present, bit 1 .rgb verified as central difference of .a, bit 2 last render derived gradients."""
+        f = C.c_int(0)
+        self._chk(self.lib.vr_volume_layout(self.h, slot, C.byref(f)))
+        return int(f.value)
 
     def set_kernel_flavour(self, flavour: int):
         self._chk(self.lib.vr_set_kernel_flavour(self.h, flavour))

@@ -40,6 +40,10 @@ struct vr_ctx {
     DevVolume vol[VR_MAX_VOLUMES] = {};
     size_t vol_bytes[VR_MAX_VOLUMES] = {};
     float2* vol_bricks[VR_MAX_VOLUMES] = {};  // per brick: (max density, max(r,g,b)) -- empty-space skipping
+    float* vol_dens[VR_MAX_VOLUMES] = {};     // scalar density plane of each slot (DevVolume::dens)
+    size_t vol_dens_cap[VR_MAX_VOLUMES] = {};  // in voxels
+    bool vol_grad_derived[VR_MAX_VOLUMES] = {};  // .rgb verified to be PreComputeGradient(false) of .a, bit for bit
+    int layout_mode = 0;                       // vr_set_volume_layout: 0 auto, 1 the reference's vec4 voxels only
     float2* merged_bricks = nullptr;           // VOLUME_MASK: (CT density max, mask rgb max), rebuilt when stale
     bool merged_stale = true;
     unsigned char* brick_dist = nullptr;       // distance field over the records in use; key below says for what
@@ -83,6 +87,7 @@ struct vr_ctx {
     int n_cus = 256;          // compute units of the device
     int default_flavour = 0;  // what flavour 0 resolves to (experiment knob VR_EXP_FLAVOUR)
     int last_flavour = 0;     // the flavour the last launch resolved to
+    bool last_otf = false;    // ... and whether it derived the gradients from the density plane
     int xcd_mode = 1;         // deal a tile's workgroups over the XCDs (VR_EXP_XCD=0: one XCD per tile)
     std::string err;
 };
@@ -152,11 +157,11 @@ int alloc_frame(vr_ctx* c)
     return VR_OK;
 }
 
-template <int V>
+template <int V, bool OTF = false>
 void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchParams& P)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK || V == V_LIGHT_INSHADER);
-#define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L>), grid, block, 0, s, P)
+#define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF>), grid, block, 0, s, P)
     if constexpr (kCanSkip) {
         if (P.brick_dist) {
             if (off32) {
@@ -308,7 +313,13 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         P.light_dif[i] = c->u.light_diffuse[i];
         P.camera_pos[i] = c->u.camera_pos[i];
     }
-    for (int i = 0; i < VR_MAX_VOLUMES; ++i) P.vol[i] = c->vol[i];
+    for (int i = 0; i < VR_MAX_VOLUMES; ++i) {
+        P.vol[i] = c->vol[i];
+        const bool plane = c->layout_mode == 0 && c->vol_dens[i] && c->vol[i].data;
+        P.vol[i].dens = plane ? c->vol_dens[i] : nullptr;
+        P.vol[i].a_base = plane ? reinterpret_cast<const char*>(c->vol_dens[i]) : reinterpret_cast<const char*>(c->vol[i].data) + 12;
+        P.vol[i].a_shift = plane ? 2 : 4;
+    }
     for (int i = 0; i < VR_MAX_TFS; ++i) P.tf[i] = c->tf[i];
     P.rank = rank;
     P.world = world;
@@ -430,6 +441,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const bool wtb = (fl == 2 || fl == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
         const int leap_mode = fl == 4 ? 1 : (fl == 5 ? 0 : (fl == 9 ? 2 : 3));
         const int dp = (fl == 7 || fl == 10) ? 4 : ((fl == 8 || fl == 11) ? 2 : 0);
+        // gradients on the fly (one-lane kernel, lit shader): the volume's .rgb is verified to be the central difference of
+        // its .a, so the eight corners are derived from the density plane -- same bits, a quarter of the footprint
+        const bool otf = variant == VR_VARIANT_LIGHT && c->layout_mode == 0 && c->vol_grad_derived[0] && P.vol[0].dens != nullptr &&
+                         !wtb && dp == 0;
+        c->last_otf = otf;
         const bool dp_pipe = fl == 10 || fl == 11;  // ... with the next round's corner loads software-pipelined  // lanes per ray (vr_dp.h): 64 / 32 workgroups per tile
         const int wpb = wtb ? 4 : c->waves_per_block;
         dim3 block((unsigned)(dp ? 256 : 64 * wpb));
@@ -486,7 +502,10 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         } else
         switch (variant) {
         case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_LIGHT: launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_LIGHT:
+            if (otf) launch_variant<V_LIGHT, true>(off32, leap_mode, grid, block, s, P);
+            else launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, P);
+            break;
         case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, P); break;
         case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, P); break;
         case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, P); break;
@@ -551,7 +570,30 @@ int refresh_bricks(vr_ctx* c, int slot)
     hipLaunchKernelGGL(brick_max_kernel, dim3((unsigned)nbricks), dim3(64), 0, c->stream, v.data, v.nx, v.ny, v.nz, bnx, bny,
                        c->vol_bricks[slot]);
     VR_HIP(c, hipGetLastError());
+    // scalar density plane + "is .rgb the central difference of .a?" (decides whether the lit shader may derive gradients)
+    const size_t n = (size_t)v.nx * v.ny * v.nz;
+    c->vol_grad_derived[slot] = false;
+    if (n > c->vol_dens_cap[slot]) {
+        if (c->vol_dens[slot]) (void)hipFree(c->vol_dens[slot]);
+        c->vol_dens[slot] = nullptr;
+        c->vol_dens_cap[slot] = 0;
+        // (+ 4 floats of slack: the 16-byte row pieces of fetch_rgba_otf never start beyond the last voxel, but may end there)
+        VR_HIP(c, hipMalloc(&c->vol_dens[slot], (n + 4) * sizeof(float)));
+        VR_HIP(c, hipMemsetAsync(c->vol_dens[slot] + n, 0, 4 * sizeof(float), c->stream));
+        c->vol_dens_cap[slot] = n;
+    }
+    hipLaunchKernelGGL(extract_density_kernel, dim3(4096), dim3(256), 0, c->stream, v.data, c->vol_dens[slot], n);
+    VR_HIP(c, hipGetLastError());
+    unsigned* d_flag = reinterpret_cast<unsigned*>(c->d_counters);
+    VR_HIP(c, hipMemsetAsync(d_flag, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(verify_gradient_kernel, dim3((unsigned)((v.nx + 255) / 256), (unsigned)v.ny, (unsigned)v.nz), dim3(256), 0,
+                       c->stream, v.data, c->vol_dens[slot], v.nx, v.ny, v.nz, d_flag);
+    VR_HIP(c, hipGetLastError());
+    unsigned flag = 1;
+    VR_HIP(c, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, c->stream));
     VR_HIP(c, hipStreamSynchronize(c->stream));
+    c->vol_grad_derived[slot] = flag == 0;
+    c->vol[slot].dens = c->vol_dens[slot];
     return VR_OK;
 }
 
@@ -757,6 +799,8 @@ void vr_destroy(vr_ctx* c)
         if (c->vol[i].data) (void)hipFree(const_cast<float4*>(c->vol[i].data));
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
         if (c->vol_bricks[i]) (void)hipFree(c->vol_bricks[i]);
+    for (int i = 0; i < VR_MAX_VOLUMES; ++i)
+        if (c->vol_dens[i]) (void)hipFree(c->vol_dens[i]);
     if (c->merged_bricks) (void)hipFree(c->merged_bricks);
     if (c->brick_dist) (void)hipFree(c->brick_dist);
     for (int i = 0; i < VR_MAX_TFS; ++i) {
@@ -1069,6 +1113,23 @@ int vr_last_kernel_flavour(vr_ctx* c)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     return c->last_flavour;
+}
+
+int vr_set_volume_layout(vr_ctx* c, int mode)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (mode < 0 || mode > 1) return fail(c, VR_ERR_INVALID_ARG, "vr_set_volume_layout: unknown mode");
+    c->layout_mode = mode;
+    return VR_OK;
+}
+
+int vr_volume_layout(vr_ctx* c, int slot, int* flags)
+{
+    if (!c || !flags) return VR_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= VR_MAX_VOLUMES) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_layout: bad slot");
+    if (!c->vol[slot].data) return fail(c, VR_ERR_NOT_READY, "vr_volume_layout: volume slot is empty");
+    *flags = (c->vol_dens[slot] ? 1 : 0) | (c->vol_grad_derived[slot] ? 2 : 0) | (c->last_otf ? 4 : 0);
+    return VR_OK;
 }
 
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)

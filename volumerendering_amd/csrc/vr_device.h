@@ -15,6 +15,14 @@ constexpr int kDistMax = 16;      // cap of the brick distance field (leaps of u
 
 struct DevVolume {
     const float4* data;  // reference layout: x fastest, (k*ny + j)*nx + i   (VolumeFile.cpp:306)
+    // Scalar density plane: the .a of every voxel, same order, 4 B per voxel (built at upload, rebuilt after every in-place
+    // change).  Every fetch that consumes .a alone reads it instead of the 16-byte voxels -- a quarter of the footprint in
+    // L2 / Infinity Cache / HBM and four times the voxels per cache line.  a_base / a_shift address either form without a
+    // branch: byte offset of voxel idx's density = idx << a_shift from a_base (the plane, or data + 12 bytes when the plane
+    // is switched off for A/B measurements).
+    const float* dens;
+    const char* a_base;
+    int a_shift;
     int nx, ny, nz;
 };
 

@@ -251,14 +251,36 @@ __device__ __forceinline__ float4 load_vec4(const float4* base, unsigned idx)
         return base[(size_t)idx];
     }
 }
+// density of voxel idx: from the scalar plane (a_shift 2) or from the .a lane of the vec4 voxels (a_shift 4, base + 12)
 template <bool OFF32>
-__device__ __forceinline__ float load_a(const float4* base, unsigned idx)
+__device__ __forceinline__ float load_a(const DevVolume& v, unsigned idx)
 {
     if constexpr (OFF32) {
-        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + ((idx << 4) + 12u));
+        return *reinterpret_cast<const float*>(v.a_base + (idx << v.a_shift));
     } else {
-        return reinterpret_cast<const float*>(base + (size_t)idx)[3];
+        return *reinterpret_cast<const float*>(v.a_base + ((size_t)idx << v.a_shift));
     }
+}
+// 4 / 2 consecutive densities of the plane starting at voxel idx (dword-aligned, not 16 / 8-byte aligned)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+template <bool OFF32>
+__device__ __forceinline__ f4u load_d4(const float* base, unsigned idx)
+{
+    if constexpr (OFF32) return *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(base) + (idx << 2));
+    else return *reinterpret_cast<const f4u*>(base + (size_t)idx);
+}
+template <bool OFF32>
+__device__ __forceinline__ float load_d1(const float* base, unsigned idx)
+{
+    if constexpr (OFF32) return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (idx << 2));
+    else return base[(size_t)idx];
+}
+template <bool OFF32>
+__device__ __forceinline__ f2u load_d2(const float* base, unsigned idx)
+{
+    if constexpr (OFF32) return *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(base) + (idx << 2));
+    else return *reinterpret_cast<const f2u*>(base + (size_t)idx);
 }
 
 __device__ __forceinline__ float tri(float v000, float v100, float v010, float v110, float v001, float v101,
@@ -300,13 +322,75 @@ template <bool OFF32>
 __device__ __forceinline__ void fetch_a(const DevVolume& v, f3 p, Fetch1& q, float& fx, float& fy, float& fz)
 {
     Cell c = make_cell(v, p);
-    q.a = load_a<OFF32>(v.data, c.o000); q.b = load_a<OFF32>(v.data, c.o100);
-    q.d = load_a<OFF32>(v.data, c.o010); q.e = load_a<OFF32>(v.data, c.o110);
-    q.f = load_a<OFF32>(v.data, c.o001); q.g = load_a<OFF32>(v.data, c.o101);
-    q.h = load_a<OFF32>(v.data, c.o011); q.i = load_a<OFF32>(v.data, c.o111);
+    q.a = load_a<OFF32>(v, c.o000); q.b = load_a<OFF32>(v, c.o100);
+    q.d = load_a<OFF32>(v, c.o010); q.e = load_a<OFF32>(v, c.o110);
+    q.f = load_a<OFF32>(v, c.o001); q.g = load_a<OFF32>(v, c.o101);
+    q.h = load_a<OFF32>(v, c.o011); q.i = load_a<OFF32>(v, c.o111);
     fx = c.fx;
     fy = c.fy;
     fz = c.fz;
+}
+
+// ---- gradients on the fly (volumes whose .rgb is verifiably PreComputeGradient(false) of their .a) ---------------------
+// VolumeFile::PreComputeGradient (VolumeFile.cpp:196-257): g = (-(p - m)) * 0.5 per axis from the +-1 neighbours' densities,
+// a neighbour outside the grid counting as 0.  The 8 corners of a trilinear cell need 32 distinct densities: the four
+// x-rows of the cell extended by one voxel either side (4 x 16 B) and the 2-voxel pieces of the rows above / below / in
+// front / behind (8 x 8 B) -- 128 B per sample, as many as the eight vec4 voxels, but out of a volume a quarter the size.
+// The same subtraction, negation and halving the preparation pass performs, so the corners come out bit-identical to the
+// stored voxels and everything downstream (interpolation, shading) is unchanged.
+__device__ __forceinline__ float grad_cd(float p, float m) { return (-(p - m)) * 0.5f; }
+// one corner the slow way (cells that touch the volume's faces): clamped texel, out-of-grid neighbours are 0
+template <bool OFF32>
+__device__ __forceinline__ float4 corner_otf(const DevVolume& v, int i, int j, int k)
+{
+    const unsigned row = (unsigned)v.nx, slab = (unsigned)v.nx * (unsigned)v.ny;
+    const unsigned c = ((unsigned)k * (unsigned)v.ny + (unsigned)j) * row + (unsigned)i;
+    const float d = load_d1<OFF32>(v.dens, c);
+    const float mx = i > 0 ? load_d1<OFF32>(v.dens, c - 1u) : 0.0f, px = i + 1 < v.nx ? load_d1<OFF32>(v.dens, c + 1u) : 0.0f;
+    const float my = j > 0 ? load_d1<OFF32>(v.dens, c - row) : 0.0f, py = j + 1 < v.ny ? load_d1<OFF32>(v.dens, c + row) : 0.0f;
+    const float mz = k > 0 ? load_d1<OFF32>(v.dens, c - slab) : 0.0f, pz = k + 1 < v.nz ? load_d1<OFF32>(v.dens, c + slab) : 0.0f;
+    return make_float4(grad_cd(px, mx), grad_cd(py, my), grad_cd(pz, mz), d);
+}
+template <bool OFF32>
+__device__ __forceinline__ void fetch_rgba_otf(const DevVolume& v, f3 p, Fetch4& q, float& fx, float& fy, float& fz)
+{
+    const float x = p.x * (float)v.nx - 0.5f, y = p.y * (float)v.ny - 0.5f, z = p.z * (float)v.nz - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+    fx = x - x0;
+    fy = y - y0;
+    fz = z - z0;
+    const int tx = (int)x0, ty = (int)y0, tz = (int)z0;  // saturating conversions, NaN -> 0
+    // the cell and its one-voxel apron strictly inside the grid: 1 <= t <= n - 3 on every axis
+    const bool inner = (unsigned)(tx - 1) < (unsigned)(v.nx - 3) && (unsigned)(ty - 1) < (unsigned)(v.ny - 3) &&
+                       (unsigned)(tz - 1) < (unsigned)(v.nz - 3) && v.nx >= 4 && v.ny >= 4 && v.nz >= 4;
+    if (__ballot(!inner) == 0) {
+        const unsigned row = (unsigned)v.nx, slab = (unsigned)v.nx * (unsigned)v.ny;
+        const unsigned b = ((unsigned)tz * (unsigned)v.ny + (unsigned)ty) * row + (unsigned)tx - 1u;  // (x0-1, y0, z0)
+        const f4u r00 = load_d4<OFF32>(v.dens, b), r10 = load_d4<OFF32>(v.dens, b + row);
+        const f4u r01 = load_d4<OFF32>(v.dens, b + slab), r11 = load_d4<OFF32>(v.dens, b + slab + row);
+        const unsigned b1 = b + 1u;
+        const f2u ym0 = load_d2<OFF32>(v.dens, b1 - row), ym1 = load_d2<OFF32>(v.dens, b1 - row + slab);
+        const f2u yp0 = load_d2<OFF32>(v.dens, b1 + 2u * row), yp1 = load_d2<OFF32>(v.dens, b1 + 2u * row + slab);
+        const f2u zm0 = load_d2<OFF32>(v.dens, b1 - slab), zm1 = load_d2<OFF32>(v.dens, b1 - slab + row);
+        const f2u zp0 = load_d2<OFF32>(v.dens, b1 + 2u * slab), zp1 = load_d2<OFF32>(v.dens, b1 + 2u * slab + row);
+        q.a = make_float4(grad_cd(r00.z, r00.x), grad_cd(r10.y, ym0.x), grad_cd(r01.y, zm0.x), r00.y);  // 000
+        q.b = make_float4(grad_cd(r00.w, r00.y), grad_cd(r10.z, ym0.y), grad_cd(r01.z, zm0.y), r00.z);  // 100
+        q.d = make_float4(grad_cd(r10.z, r10.x), grad_cd(yp0.x, r00.y), grad_cd(r11.y, zm1.x), r10.y);  // 010
+        q.e = make_float4(grad_cd(r10.w, r10.y), grad_cd(yp0.y, r00.z), grad_cd(r11.z, zm1.y), r10.z);  // 110
+        q.f = make_float4(grad_cd(r01.z, r01.x), grad_cd(r11.y, ym1.x), grad_cd(zp0.x, r00.y), r01.y);  // 001
+        q.g = make_float4(grad_cd(r01.w, r01.y), grad_cd(r11.z, ym1.y), grad_cd(zp0.y, r00.z), r01.z);  // 101
+        q.h = make_float4(grad_cd(r11.z, r11.x), grad_cd(yp1.x, r01.y), grad_cd(zp1.x, r10.y), r11.y);  // 011
+        q.i = make_float4(grad_cd(r11.w, r11.y), grad_cd(yp1.y, r01.z), grad_cd(zp1.y, r10.z), r11.z);  // 111
+        return;
+    }
+    int i0, i1, j0, j1, k0, k1;
+    texel_pair(x0, v.nx, i0, i1);
+    texel_pair(y0, v.ny, j0, j1);
+    texel_pair(z0, v.nz, k0, k1);
+    q.a = corner_otf<OFF32>(v, i0, j0, k0); q.b = corner_otf<OFF32>(v, i1, j0, k0);
+    q.d = corner_otf<OFF32>(v, i0, j1, k0); q.e = corner_otf<OFF32>(v, i1, j1, k0);
+    q.f = corner_otf<OFF32>(v, i0, j0, k1); q.g = corner_otf<OFF32>(v, i1, j0, k1);
+    q.h = corner_otf<OFF32>(v, i0, j1, k1); q.i = corner_otf<OFF32>(v, i1, j1, k1);
 }
 // Two channels at a time (packed f32 on the register halves the 16-byte loads deliver: no shuffling).  Per lane
 // and per channel the operations and their order are those of tri(): a + (b - a) * t, separately rounded.
@@ -338,13 +422,14 @@ __device__ __forceinline__ float interp_a(const Fetch1& q, float fx, float fy, f
     return tri(q.a, q.b, q.d, q.e, q.f, q.g, q.h, q.i, fx, fy, fz);
 }
 
-// textureSample(vol, samplerLin, p) -> all four channels
-template <bool OFF32>
+// textureSample(vol, samplerLin, p) -> all four channels (OTF: the corners' gradients derived from the density plane)
+template <bool OFF32, bool OTF = false>
 __device__ __forceinline__ float4 tex3_rgba(const DevVolume& v, f3 p)
 {
     Fetch4 q;
     float fx, fy, fz;
-    fetch_rgba<OFF32>(v, p, q, fx, fy, fz);
+    if constexpr (OTF) fetch_rgba_otf<OFF32>(v, p, q, fx, fy, fz);
+    else fetch_rgba<OFF32>(v, p, q, fx, fy, fz);
     const v2f zw = interp_zw(q, fx, fy, fz), xy = interp_xy(q, fx, fy, fz);
     return make_float4(xy.x, xy.y, zw.x, zw.y);
 }
@@ -529,7 +614,7 @@ struct Src {
 };
 // (start = the ray's first position and dst_a = the opacity accumulated so far are read by the illustrative shader only,
 // ss = the ray's step size after the variable-step override by the in-shader gradient only)
-template <int V, bool OFF32>
+template <int V, bool OFF32, bool OTF = false>
 __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 start = f3{0.0f, 0.0f, 0.0f}, float dst_a = 0.0f,
                                           float ss = 0.0f)
 {
@@ -540,7 +625,7 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
         o.rgb = t.rgb;
         o.a = t.opacity;
     } else if constexpr (V == V_LIGHT) {
-        float4 v = tex3_rgba<OFF32>(P.vol[0], p);
+        float4 v = tex3_rgba<OFF32, OTF>(P.vol[0], p);
         TfSample t = tf_lookup(P.tf[0], v.w);
         f3 N = normalize3(mk3(v.x, v.y, v.z));
         f3 s = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
@@ -639,7 +724,7 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     }
     return o;
 }
-template <int V, bool OFF32>
+template <int V, bool OFF32, bool OTF = false>
 __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst, f3 start, float ss)
 {
     if constexpr (V == V_LIGHT) {
@@ -648,7 +733,8 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         // normalize3 / shade / blend.
         Fetch4 q;
         float fx, fy, fz;
-        fetch_rgba<OFF32>(P.vol[0], p, q, fx, fy, fz);
+        if constexpr (OTF) fetch_rgba_otf<OFF32>(P.vol[0], p, q, fx, fy, fz);
+        else fetch_rgba<OFF32>(P.vol[0], p, q, fx, fy, fz);
         const v2f zw = interp_zw(q, fx, fy, fz);  // (gradient z, density)
         const TfFetch tq = tf_fetch(P.tf[0], zw.y);
         const v2f gxy = interp_xy(q, fx, fy, fz);
@@ -678,7 +764,7 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         dst.z = om * src_b + dst.z;
         dst.w = om * opacity + dst.w;
     } else {
-        const Src s = sample_src<V, OFF32>(P, p, w, start, dst.w, ss);
+        const Src s = sample_src<V, OFF32, OTF>(P, p, w, start, dst.w, ss);
         blend(s.rgb, s.a, dst);
     }
 }
@@ -875,7 +961,9 @@ __device__ __forceinline__ float leap_axis(float p, float s, float bs, int nb, i
     return room * (__builtin_amdgcn_rcpf(fabsf(s)) * 0.999f);  // approximate reciprocal, scaled down: never too large
 }
 
-template <int V, bool OFF32, bool SKIP, int LEAP>
+// OTF (V_LIGHT only): the corners' gradients are derived from the density plane (fetch_rgba_otf) instead of read from
+// the vec4 voxels; the host asks for it when the volume's .rgb is verified to be PreComputeGradient(false) of its .a.
+template <int V, bool OFF32, bool SKIP, int LEAP, bool OTF = false>
 __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
 {
     const unsigned long long t_start = wall_clock64();
@@ -945,7 +1033,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                 // wavefront whose rays are all inside tissue skips that block, and the eight corner loads it has issued
                 // for the next step (kPipe) stay in flight from the shading of one step to the interpolation of the next.
                 constexpr bool kRun = SKIP && (LEAP >= 2);                              // wave-uniform runs of identity steps
-                constexpr bool kPipe = (V == V_LIGHT || V == V_BASIC) && LEAP != 3 && LEAP != 1;  // corner prefetch
+                constexpr bool kPipe = (V == V_LIGHT || V == V_BASIC) && LEAP != 3 && LEAP != 1 && !OTF;  // corner prefetch
                 unsigned D = 0, Dn = 0, Dq = 0, Dn2 = 0;
                 bool have = false;   // the previous iteration sampled: corners of p requested (F4 / F1), Dn arrived
                 bool stale = false;  // ... and the one before did, this one did not: Dq was not requested
@@ -1072,7 +1160,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                                     blend(t.rgb, t.opacity, dst);
                                 }
                             } else {
-                                sample_and_blend<V, OFF32>(P, p, w, dst, ray.start, step_size);
+                                sample_and_blend<V, OFF32, OTF>(P, p, w, dst, ray.start, step_size);
                             }
                             ++fetched;
                             ++blends;
@@ -1285,6 +1373,34 @@ __global__ void merge_bricks_kernel(const float2* __restrict__ density_vol, cons
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = make_float2(density_vol[i].x, mask_vol[i].y);
+}
+
+// ---- density plane / derived-gradient check (run with the brick records after every upload or in-place change) -------
+__global__ void extract_density_kernel(const float4* __restrict__ vol, float* __restrict__ dens, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dens[i] = vol[i].w;
+}
+// *mismatch != 0 afterwards unless EVERY voxel's .rgb has exactly the bits PreComputeGradient(false) computes from the
+// .a plane ((-(p - m)) * 0.5 per axis, neighbours outside the grid = 0; NaNs never match).
+__global__ void verify_gradient_kernel(const float4* __restrict__ vol, const float* __restrict__ dens, int nx, int ny, int nz,
+                                       unsigned* __restrict__ mismatch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, z = blockIdx.z;
+    bool bad = false;
+    if (x < nx) {
+        const size_t c = ((size_t)z * ny + y) * nx + x;
+        const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+        const float mx = x > 0 ? dens[c - 1] : 0.0f, px = x + 1 < nx ? dens[c + 1] : 0.0f;
+        const float my = y > 0 ? dens[c - sy] : 0.0f, py = y + 1 < ny ? dens[c + sy] : 0.0f;
+        const float mz = z > 0 ? dens[c - sz] : 0.0f, pz = z + 1 < nz ? dens[c + sz] : 0.0f;
+        const float4 v = vol[c];
+        bad = __float_as_uint(v.x) != __float_as_uint(grad_cd(px, mx)) || __float_as_uint(v.y) != __float_as_uint(grad_cd(py, my)) ||
+              __float_as_uint(v.z) != __float_as_uint(grad_cd(pz, mz)) || v.x != v.x || v.y != v.y || v.z != v.z;
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(mismatch, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ data preparation
