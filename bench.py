@@ -70,6 +70,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class stdout_to_stderr:
+    """File-descriptor level: whatever native libraries print on stdout inside the block (RCCL's version banner, gloo's
+    connection notes) goes to stderr, so that stdout carries the ONE JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def host_cores():
     """CPUs this process can really use: its affinity mask, cut down to the cgroup's CPU quota when one is set (the GPU
     boxes expose every host CPU in the mask but grant a share)."""
@@ -211,8 +226,9 @@ def main():
     ap.add_argument("--no-regimes", action="store_true", help="skip the air x TF regime table (C3)")
     ap.add_argument("--pmc-extra", action="store_true", help="more counter passes (L1 / TA / wait states); all counters go into `pmc`")
     ap.add_argument("--flavour", type=int, default=0)
-    ap.add_argument("--layout", type=int, default=0, choices=[0, 1],
-                    help="vr_set_volume_layout: 0 density plane + gradients on the fly where verified, 1 the reference's vec4 voxels only")
+    ap.add_argument("--layout", type=int, default=0, choices=[0, 1, 2],
+                    help="vr_set_volume_layout: 0 density plane for .a fetches, 1 the reference's vec4 voxels only, 2 = 0 + lit "
+                         "gradients derived on the fly from the plane")
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="frames in flight in the overlapped leg (1 = that leg is a second serial leg)")
@@ -233,27 +249,27 @@ def main():
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
-    # VR_BENCH_DEVICE / VR_BENCH_BACKEND exist only to rehearse the N > 1 code path on a one-GPU box (all ranks on
-    # device 0, gloo through host memory); the real multi-GPU run uses one GPU per rank and RCCL.
+    # VR_BENCH_DEVICE / VR_BENCH_BACKEND=gloo exist only to rehearse the N > 1 bookkeeping on a one-GPU box (all ranks on
+    # device 0, tiles gathered with gloo through host memory: RCCL refuses two ranks on one device); the real multi-GPU
+    # run uses one GPU per rank and the C++ frame loop of libvr_mgpu.so (ncclGather over xGMI).
     device_index = int(os.environ.get("VR_BENCH_DEVICE", local_rank))
-    backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("VR_BENCH_BACKEND", "rccl")
     torch.cuda.set_device(device_index)
     # VR_BENCH_SELF_GATHER=1 (rehearsal): take the multi-rank code path -- tile render, RCCL gather, un-permute -- with
     # a world of one, so that the RCCL calls and their stream ordering can be exercised on a one-GPU box
     multi = world > 1 or bool(os.environ.get("VR_BENCH_SELF_GATHER"))
     dist = None
     if multi:
+        # torch.distributed (gloo) is the CONTROL plane only: it carries the 128-byte RCCL id from rank 0 to the others and
+        # provides the barrier of the timing contract; no frame data goes through it (except in the gloo rehearsal)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist_mod
         dist = dist_mod
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend=backend)
-    comm_dev = "cuda" if backend == "nccl" else "cpu"
+        with stdout_to_stderr():
+            dist.init_process_group(backend="gloo")
 
     n, W, H, vname = wl.WORKLOADS[args.workload]
     app = host.Application(W, H, device_index)
@@ -273,50 +289,46 @@ def main():
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max_flight - 1)]
     for st in streams[1:]:
         st.wait_stream(streams[0])
-    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(max_flight)]
-    if multi:
-        # every frame's gather and un-permute completes inside the timed region
+    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(max_flight)] if not multi else []
+    mg = None
+    if multi and backend == "rccl":
+        from volumerendering_amd import mgpu
+        idt = torch.zeros(mgpu.ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            idt = torch.tensor(list(mgpu.unique_id()), dtype=torch.uint8)
+        with stdout_to_stderr():
+            dist.broadcast(idt, 0)
+            mg = mgpu.MultiGpu(ctx.h, rank, world, bytes(idt.tolist()))  # ncclCommInitRank: collective
+            mg.frame_async(variant)  # first collective (RCCL sets its channels up here), outside every timed region
+            mg.wait()
+    elif multi:  # gloo rehearsal
         my_tiles = [torch.zeros((tpr_max * tile_floats,), dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered = [torch.zeros((world, tpr_max * tile_floats), dtype=torch.float32, device="cuda") for _ in range(2)] \
             if rank == 0 else [None, None]
-        gather_list = [[g[r] for r in range(world)] for g in gathered] if rank == 0 else [None, None]
-
-    def finish(b, work):
-        """Frame in buffer set b: wait for its gather (orders the current stream behind it, no host block), un-permute."""
-        if work is not None:
-            work.wait()
-        if rank == 0:
-            ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        frames = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
 
     def run_frames(n_frames, nbuf):
         if not multi:
             for k in range(n_frames):
                 ctx.render_async(variant, frames[k % nbuf].data_ptr(), streams[k % nbuf].cuda_stream)
             return
-        pending = [None, None]  # per buffer set: (work handle,) of the frame that last used it
-        for k in range(n_frames):
-            b = k % nbuf
-            with torch.cuda.stream(streams[b]):
-                if pending[b] is not None:  # the previous user of these buffers: its tiles must have left before reuse
-                    finish(b, pending[b][0])
-                ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), streams[b].cuda_stream)
-                if backend == "nccl":
-                    # RCCL over xGMI: every peer sends straight to the root (7 links in parallel, not a ring); the
-                    # collective is ordered behind this stream's render and runs on RCCL's own stream
-                    work = dist.gather(my_tiles[b], gather_list[b], dst=0, async_op=True)
-                else:  # rehearsal only: through host memory, synchronous
-                    host_list = [torch.empty(my_tiles[b].numel()) for _ in range(world)] if rank == 0 else None
-                    dist.gather(my_tiles[b].cpu(), host_list, dst=0)
-                    if rank == 0:
-                        gathered[b].copy_(torch.stack(host_list))
-                    work = None
-                pending[b] = (work,)
-        order = [((n_frames + j) % nbuf) for j in range(nbuf)]  # the oldest outstanding frame first
-        for b in order:
-            if pending[b] is not None:
-                with torch.cuda.stream(streams[b]):
-                    finish(b, pending[b][0])
-                pending[b] = None
+        if mg is not None:
+            # the C++ loop: every rank renders its tiles, ncclGather, the root un-permutes; two buffer sets, so up to two
+            # frames are in flight -- nbuf = 1 waits for every frame before the next one is enqueued
+            for _ in range(n_frames):
+                mg.frame_async(variant)
+                if nbuf == 1:
+                    mg.wait()
+            mg.wait()
+            return
+        for k in range(n_frames):  # gloo rehearsal: synchronous, through host memory
+            b = k & 1
+            ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), streams[0].cuda_stream)
+            host_list = [torch.empty(my_tiles[b].numel()) for _ in range(world)] if rank == 0 else None
+            dist.gather(my_tiles[b].cpu(), host_list, dst=0)
+            if rank == 0:
+                gathered[b].copy_(torch.stack(host_list))
+                ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames[b].data_ptr(), streams[0].cuda_stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -338,8 +350,8 @@ def main():
             run_frames(min_events - n_steps, nbuf)
             sync_all()
         kt = ctx.kernel_times(min(max(n_steps, min_events), 256))
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+        if dist is not None:  # MAX over ranks
+            t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, kt
@@ -350,8 +362,10 @@ def main():
 
     # composited samples / covered pixels / samples whose voxels were fetched, for this rank's share of the frame
     my_samples, my_covered, my_fetched = ctx.counters()
-    if dist is not None:
-        s = torch.tensor([my_samples, my_covered, my_fetched], dtype=torch.int64, device=comm_dev)
+    if mg is not None:  # summed over the ranks by the C++ driver (ncclAllReduce)
+        (total_samples, covered, total_fetched), _ = mg.reduce(0.0)
+    elif dist is not None:
+        s = torch.tensor([my_samples, my_covered, my_fetched], dtype=torch.int64)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_samples, covered, total_fetched = int(s[0].item()), int(s[1].item()), int(s[2].item())
     else:
@@ -375,7 +389,11 @@ def main():
     alg_composited = my_samples * bs + 16 * owned_px  # SURVEY 8d's figure: every composited sample priced as a fetch
     vol_bytes = sum(int(np.prod(v.GetSize())) * 16 for v in vols)
 
-    gpu_frame = frames[0].cpu().numpy() if rank == 0 else None  # the serial leg's / the oldest buffer's frame
+    if mg is not None:
+        gpu_frames = [mg.download(w, W, H) for w in (0, 1)] if rank == 0 else []
+    else:
+        gpu_frames = [f.cpu().numpy() for f in frames[:2]] if rank == 0 else []
+    gpu_frame = gpu_frames[0] if gpu_frames else None
 
     # ---- roofline: measured fabric bytes (rocprofv3 PMC passes on the same scene, launched from here) -------------
     pmc, pmc_note = ({}, "skipped")
@@ -448,7 +466,7 @@ def main():
             pass
 
     part = "single GPU" if not multi else f"64x64 image tiles interleaved over {world} GPUs + " + \
-        ("RCCL gather (torch.distributed nccl backend)" if backend == "nccl" else f"{backend} gather through host memory (rehearsal)")
+        ((mg.backend() + " (C++ frame loop, libvr_mgpu.so)") if mg is not None else "gloo gather through host memory (rehearsal)")
     out = {
         "metric": "Gsamples/s", "value": over["value"], "unit": "Gsamples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": over["ms_per_step"], "fps": over["fps"],
@@ -460,7 +478,7 @@ def main():
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
             "covered_pixels": covered, "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
             "volume_layout": ("density plane for .a fetches" + (", corner gradients derived on the fly" if layout_flags & 4 else ""))
-                             if args.layout == 0 else "reference vec4 voxels only",
+                             if args.layout != 1 else "reference vec4 voxels only",
         },
         "serial": serial, "overlapped": over, "roofline": roofline,
     }
@@ -514,16 +532,17 @@ def main():
         parity, base = oracle_legs(app, variant, vols, W, H, gpu_frame, total_samples)
         out["parity"] = parity
         out["cpu_baseline"] = base
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0 and os.environ.get("VR_BENCH_CHECK_FRAME"):
-        # rehearsal aid: the gathered frame must equal a single-rank render of the same scene, bit for bit
+    if rank == 0 and multi:
+        # the gathered frames must equal a single-rank render of the same scene, bit for bit (cheap: one more frame)
         ctx.render_async(variant, 0, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         ref, _, _ = ctx.download()
-        same = all(bool(np.array_equal(ref.view(np.uint32), f.cpu().numpy().view(np.uint32))) for f in frames[:2])
-        out["config"]["frame_equals_single_rank_render"] = same
+        out["config"]["frame_equals_single_rank_render"] = all(bool(np.array_equal(ref.view(np.uint32), f.view(np.uint32))) for f in gpu_frames)
+    if mg is not None:
+        mg.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
     app.close()

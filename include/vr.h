@@ -223,6 +223,9 @@ int vr_last_timing(vr_ctx* ctx, float* kernel_ms, float* total_ms);
 int vr_kernel_times(vr_ctx* ctx, float* out_ms, int capacity);
 int vr_reset_kernel_times(vr_ctx* ctx);
 
+/* Viewport size and HIP device ordinal of a context (any pointer may be NULL). */
+int vr_viewport(const vr_ctx* ctx, uint32_t* width, uint32_t* height, int* device_id);
+
 /* Device pointer of the ctx-owned frame buffer (W*H*4 floats) written by vr_render. */
 void* vr_frame_device_ptr(vr_ctx* ctx);
 
@@ -253,12 +256,14 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *      the default uses for small launches)                                                                  */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 
-/* Volume layout in HBM (A/B measurements; frames and counts are bit-identical either way).
- *   0  auto (default): next to the reference's vec4 voxels every slot keeps a scalar f32 density plane (4 B / voxel);
- *      fetches that consume .a alone (BasicVolumeApp.wgsl:171 and the density / dose fetches of the other shaders) read
- *      it, and the lit shader derives the eight corner gradients from it on the fly when the slot's .rgb is verified, at
- *      upload, to be VolumeFile::PreComputeGradient(false) of its .a bit for bit (VolumeFile.cpp:196-257)
+/* Volume layout in HBM (A/B measurements; frames and counts are bit-identical in every mode).
+ *   0  default: next to the reference's vec4 voxels every slot keeps a scalar f32 density plane (4 B / voxel); fetches
+ *      that consume .a alone (BasicVolumeApp.wgsl:171 and the density / dose fetches of the other shaders) read it
  *   1  the reference's RGBA32F voxels only (16 B / voxel; what round 1 measured)
+ *   2  0 + the lit shader derives the eight corner gradients from the plane on the fly when the slot's .rgb is verified,
+ *      at upload, to be VolumeFile::PreComputeGradient(false) of its .a bit for bit (VolumeFile.cpp:196-257): a quarter of
+ *      the footprint and 0.69x the fabric traffic, but 1.5x the L1 accesses of the row-major plane -- measured slower
+ *      (DESIGN.md section 4.5), kept for A/B
  * vr_volume_layout: *flags bit 0 = density plane present, bit 1 = .rgb verified as the central difference of .a,
  * bit 2 = the last render derived its gradients on the fly.                                                    */
 int vr_set_volume_layout(vr_ctx* ctx, int mode);

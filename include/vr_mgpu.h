@@ -1,0 +1,87 @@
+/*
+ * vr_mgpu.h -- C ABI of the multi-GPU frame loop (libvr_mgpu.so): image-tile partition of one frame over the GPUs of
+ * one node, one RCCL gather over xGMI per frame, un-permute on the root.
+ *
+ * What it replaces: nothing in the reference -- gutiKristian/VolumeRendering renders on one device
+ * (WebgpuLib/src/Base/GraphicsContext.h:35-42, static singletons); the caller is still Application::OnRender
+ * (App/src/Application.cpp:121-239), once per frame.  The partition is the one BASELINE.json's north_star names:
+ * the frame is cut into 64x64 tiles, tile t = ty * tiles_x + tx is owned by rank t % world (interleaved, so every
+ * rank gets an even sample of the screen), the volume and the tables are replicated, the uniforms are identical on
+ * every rank.  Each rank renders its tiles packed (vr_render_tiles_async, include/vr.h), ncclGather
+ * (/opt/rocm/include/rccl/rccl.h) delivers every rank's segment to the root -- every peer owns a direct xGMI link to
+ * the root, so the transfers run side by side and are not ring-bound -- and vr_unpack_tiles_async scatters them into
+ * the frame.  No other collective exists on the path.
+ *
+ * Two ways to drive it, same frame loop behind both:
+ *   one process per GPU   vr_mgpu_unique_id on rank 0, the 128 bytes carried to the other ranks by the launcher
+ *                         (MPI, a torch.distributed store, a file ...), then vr_mgpu_create on every rank with the
+ *                         rank's own vr_ctx.  This is what bench.py --gpus N uses under torch.distributed.run.
+ *   one process, N GPUs   vr_mgpu_create_local: the driver owns N contexts (one per device), ncclCommInitAll, and
+ *                         issues the per-device calls of a frame inside one ncclGroupStart / ncclGroupEnd.  Scene
+ *                         resources are uploaded to every context (vr_mgpu_context(m, i)).
+ *
+ * Frames are pipelined two deep: frame k+1 renders while frame k's tiles travel and are un-permuted (two tile /
+ * gather / frame buffer sets, used alternately).  vr_mgpu_frame_async never blocks the host on the GPU except to
+ * bound the pipeline at two frames; vr_mgpu_wait drains it.
+ *
+ * Conventions as in vr.h: plain C, 0 = ok, negative = vr_status, message via vr_mgpu_last_error; no exception
+ * crosses the boundary; one thread at a time per handle.
+ */
+#ifndef VR_MGPU_H_
+#define VR_MGPU_H_
+
+#include <stdint.h>
+
+#include "vr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_MGPU_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+
+typedef struct vr_mgpu vr_mgpu;
+
+/* ncclGetUniqueId: call on ONE rank, distribute the bytes to all ranks out of band. */
+int vr_mgpu_unique_id(void* id128);
+
+/* One process per GPU.  `ctx` is this rank's context (created on this rank's device; the driver borrows it and never
+ * destroys it); rank / world as in vr_render_tiles; id128 from vr_mgpu_unique_id.  Collective: every rank must call
+ * it (ncclCommInitRank).                                                                                            */
+int vr_mgpu_create(vr_mgpu** out, vr_ctx* ctx, int rank, int world, const void* id128);
+
+/* One process, n_devices GPUs: creates one W x H context per device (owned by the driver) and the communicators
+ * (ncclCommInitAll).  Local rank i renders on device_ids[i]; rank 0 is the root.                                    */
+int vr_mgpu_create_local(vr_mgpu** out, uint32_t width, uint32_t height, const int* device_ids, int n_devices);
+
+void vr_mgpu_destroy(vr_mgpu* m);
+const char* vr_mgpu_last_error(const vr_mgpu* m);
+
+int vr_mgpu_world(const vr_mgpu* m);        /* ranks in the partition                               */
+int vr_mgpu_local_ranks(const vr_mgpu* m);  /* ranks driven by this process (1, or n_devices)      */
+vr_ctx* vr_mgpu_context(vr_mgpu* m, int local_rank);
+
+/* Enqueue one frame: every local rank renders its tiles, the gather, the root's un-permute.  Uses the uniforms,
+ * volumes and tables currently set on each context.  Returns the buffer set (0 / 1) the frame will land in.        */
+int vr_mgpu_frame_async(vr_mgpu* m, int variant);
+
+/* Block until every enqueued frame is complete (on the root: assembled in its frame buffer).                      */
+int vr_mgpu_wait(vr_mgpu* m);
+
+/* Root only (NULL elsewhere): device pointer of assembled frame buffer `which` (W*H*4 floats).                    */
+void* vr_mgpu_frame_device_ptr(vr_mgpu* m, int which);
+
+/* Root only: waits, then copies frame buffer `which` to the host (W*H*4 floats).                                  */
+int vr_mgpu_download(vr_mgpu* m, int which, float* frag_rgba);
+
+/* Sum over ALL ranks of the last frame's counters (composited samples, covered pixels, fetched samples) and the
+ * maximum over all ranks of `local_value` (e.g. a wall time): two tiny ncclAllReduce calls, blocking.  Collective. */
+int vr_mgpu_reduce(vr_mgpu* m, uint64_t counters_sum[3], double local_value, double* max_value);
+
+/* Which transport the gather uses, for reports: "RCCL <version> ncclGather".                                      */
+const char* vr_mgpu_backend(const vr_mgpu* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR_MGPU_H_ */

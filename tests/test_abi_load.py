@@ -23,6 +23,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.vr_abi_version() == 1
 
 
+def test_multi_gpu_library_exports_every_declared_symbol():
+    """libvr_mgpu.so (the C++ multi-GPU frame loop: RCCL gather) loads without a GPU and exports what vr_mgpu.h declares;
+    ncclGather is resolved against RCCL."""
+    from volumerendering_amd import mgpu
+    lib = mgpu.load()
+    header = open(os.path.join(ROOT, "include", "vr_mgpu.h")).read()
+    declared = set(re.findall(r"\b(vr_mgpu_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(mgpu.ABI_SYMBOLS), declared ^ set(mgpu.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    und = subprocess.run(["nm", "-D", "--undefined-only", mgpu.LIB_PATH], capture_output=True, text=True).stdout
+    for sym in ("ncclGather", "ncclCommInitRank", "ncclCommInitAll", "ncclGroupStart", "vr_render_tiles_async", "vr_unpack_tiles_async"):
+        assert sym in und, sym
+    assert "rccl" in subprocess.run(["ldd", mgpu.LIB_PATH], capture_output=True, text=True).stdout
+
+
 def test_uniform_struct_layout_matches_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vr.h"\nint main(){printf("%zu %zu %zu %zu %zu",'
@@ -54,7 +70,7 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "vr_oracle" not in txt and "oracle_binding" not in txt and "host_ref" not in txt, f
-    for so in ("libvr_hip.so", "libvr_host.so"):
+    for so in ("libvr_hip.so", "libvr_host.so", "libvr_mgpu.so"):
         p = os.path.join(pkg, so)
         if os.path.exists(p):
             out = subprocess.run(["ldd", p], capture_output=True, text=True).stdout

@@ -518,9 +518,9 @@ def test_two_frames_in_flight_on_two_streams(ctx):
 
 # ---- volume layout in HBM: density plane + gradients on the fly (vr_set_volume_layout) --------------------------------
 def test_density_plane_and_on_the_fly_gradients_are_exact(ctx):
-    """Layout 0 (density plane for .a fetches; the lit shader derives the corner gradients from it when the voxels' .rgb is
-    verified to be PreComputeGradient(false) of .a) and layout 1 (the reference's vec4 voxels only) give the same bits and
-    counts as the oracle, for every shader; the verification recognises derived and foreign gradients."""
+    """Layout 0 (density plane for .a fetches), 1 (the reference's vec4 voxels only) and 2 (0 + the lit shader derives the
+    corner gradients from the plane when the voxels' .rgb is verified to be PreComputeGradient(false) of .a) give the same
+    bits and counts as the oracle, for every shader; the verification recognises derived and foreign gradients."""
     W, H = 88, 60
     step, count = hr.stepping_params(24, 24, 24)
     try:
@@ -530,7 +530,7 @@ def test_density_plane_and_on_the_fly_gradients_are_exact(ctx):
                 args = dict(steps_count=count, step_size=step)
                 args.update(kw)
                 u = hr.make_uniforms(W, H, **args)
-                for mode in (0, 1):
+                for mode in (0, 1, 2):
                     ctx.set_volume_layout(mode)
                     for fl in (0, 6, 1):
                         ctx.set_kernel_flavour(fl)
@@ -538,7 +538,7 @@ def test_density_plane_and_on_the_fly_gradients_are_exact(ctx):
                         if variant == capi.LIGHT:
                             flags = ctx.volume_layout(0)
                             assert flags & 1 and flags & 2            # plane present, gradient recognised as derived
-                            assert bool(flags & 4) == (mode == 0 and ctx.last_kernel_flavour() in (1, 4, 5, 6, 9))
+                            assert bool(flags & 4) == (mode == 2 and ctx.last_kernel_flavour() in (1, 4, 5, 6, 9))
     finally:
         ctx.set_volume_layout(0)
         ctx.set_kernel_flavour(0)
@@ -547,10 +547,11 @@ def test_density_plane_and_on_the_fly_gradients_are_exact(ctx):
 def test_gradient_verification_and_boundary_cells(ctx):
     W, H = 72, 56
     ctx.set_kernel_flavour(6)
+    ctx.set_volume_layout(2)
     try:
         # tiny and ragged grids: cells touch the faces everywhere (n < 4: the generic corner path only)
         for shape in [(3, 3, 3), (2, 5, 9), (4, 4, 4), (5, 4, 7), (1, 8, 8), (9, 1, 6)]:
-            raw = hr.ct_phantom_raw(16)[: shape[0], : shape[1], : shape[2]]
+            raw = hr.ct_phantom_raw(16)[5: 5 + shape[0], 4: 4 + shape[1], 3: 3 + shape[2]]  # from inside the body
             v = ob.precompute_gradient(ob.normalize_data(hr.raw_to_vec4(raw)))
             tf = (hr.default_opacity_tf(32), hr.default_color_tf(32))
             for cam in (dict(), dict(yaw=1.9, pitch=0.8, distance=0.75)):
@@ -596,5 +597,43 @@ def test_gradient_verification_and_boundary_cells(ctx):
         frag, _, ns = ctx.download()
         ref, n_ref, _ = ob.render(capi.LIGHT, u, [base], [(hr.default_opacity_tf(32), hr.default_color_tf(32))], W, H, nthreads=8)
         assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref and ctx.volume_layout(0) & 4
+    finally:
+        ctx.set_kernel_flavour(0)
+        ctx.set_volume_layout(0)
+
+
+def test_longest_first_launch_order_changes_nothing(ctx):
+    """From the second frame on the workgroups take their blocks in the order of the previous frame's longest ray chains
+    (MarchParams::order, a permutation sorted on the device): same bits, same counts, frame after frame, for the
+    one-lane and the depth-parallel kernels, full frames and one rank's tiles, and across a change of the camera."""
+    W, H = 330, 210
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(capi.LIGHT, n=32)
+    step, count = hr.stepping_params(32, 32, 32)
+    try:
+        for fl in (6, 11, 10, 1):
+            ctx.set_kernel_flavour(fl)
+            for cam in (dict(), dict(yaw=2.0, pitch=-0.5, distance=0.9)):
+                u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam)
+                ref, n_ref, cov_ref = ob.render(capi.LIGHT, u, vols, tfs, W, H, nthreads=8)
+                for i, v in enumerate(vols):
+                    ctx.volume_upload(i, v)
+                ctx.tf_upload(0, *tfs[0])
+                ctx.set_uniforms(vt.to_capi_uniforms(u))
+                for _ in range(4):   # frame 1: index order; frames 2..4: sorted by the frame before
+                    ctx.render(capi.LIGHT)
+                    frag, _, ns = ctx.download()
+                    assert np.array_equal(vt.bits(frag), vt.bits(ref)) and ns == n_ref and ctx.covered_pixels() == cov_ref, fl
+                    trace = ctx.block_trace()
+                    assert int(trace[:, 0].sum()) == n_ref   # the per-block records still add up (indexed by logical block)
+                for _ in range(3):
+                    total = 0
+                    for r in range(3):
+                        ctx.render_tiles(capi.LIGHT, r, 3)
+                        t, cnt = ctx.download_tiles(ctx.tile_count(r, 3))
+                        total += cnt
+                        from volumerendering_amd import tiles
+                        assert np.array_equal(vt.bits(t), vt.bits(tiles.pack(ref, r, 3))), (fl, r)
+                    assert total == n_ref
     finally:
         ctx.set_kernel_flavour(0)

@@ -51,6 +51,22 @@ def build_host(force: bool = False) -> str | None:
     return target
 
 
+def build_mgpu(force: bool = False) -> str:
+    """libvr_mgpu.so: the multi-GPU frame loop (C++ host code on the HIP runtime + RCCL, above the C ABI of libvr_hip.so)."""
+    target = os.path.join(HERE, "libvr_mgpu.so")
+    src = os.path.join(CSRC, "mgpu", "vr_mgpu.cpp")
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    deps = [src, os.path.join(inc, "vr_mgpu.h"), os.path.join(inc, "vr.h")]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if force or _newer(target, deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", inc,
+                        "-I", os.path.join(rocm, "include"), "-o", target, src, "-L", HERE, "-lvr_hip",
+                        "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl",
+                        "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")], check=True)
+    return target
+
+
 def build_all(force: bool = False):
     build_hip(force)
     build_host(force)
+    build_mgpu(force)

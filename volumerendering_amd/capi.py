@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
-    "vr_set_volume_layout", "vr_volume_layout",
+    "vr_set_volume_layout", "vr_volume_layout", "vr_viewport",
 ]
 
 
@@ -275,7 +275,7 @@ class Context:
         return self._chk(self.lib.vr_last_kernel_flavour(self.h))
 
     def set_volume_layout(self, mode: int):
-        """0 auto (density plane + on-the-fly gradients where verified), 1 the reference's vec4 voxels only."""
+        """0 density plane for .a fetches (default), 1 the reference's vec4 voxels only, 2 = 0 + lit gradients on the fly."""
         self._chk(self.lib.vr_set_volume_layout(self.h, mode))
 
     def volume_layout(self, slot: int) -> int:

@@ -1,0 +1,331 @@
+// vr_mgpu.cpp -- the multi-GPU frame loop behind include/vr_mgpu.h: image tiles interleaved over the ranks, one RCCL
+// gather per frame (every peer has a direct xGMI link to the root: the transfers run side by side), un-permute on the
+// root, frames pipelined two deep.  C++ host code on the HIP runtime + RCCL; the rendering itself goes through the C ABI
+// of libvr_hip.so (vr_render_tiles_async / vr_unpack_tiles_async).  No reference counterpart: the reference is a
+// single-device application (WebgpuLib/src/Base/GraphicsContext.h:35-42).
+#include "../../../include/vr_mgpu.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int kTilePx = 64;
+constexpr int kSlots = 2;  // frames in flight
+
+thread_local std::string g_create_error;
+
+struct Rank {
+    int device = 0;
+    int rank = 0;
+    vr_ctx* ctx = nullptr;
+    bool own_ctx = false;
+    ncclComm_t comm = nullptr;
+    hipStream_t s_render[kSlots] = {}, s_comm = nullptr;
+    hipEvent_t ev_render[kSlots] = {}, ev_done[kSlots] = {};
+    bool used[kSlots] = {};
+    float* tiles[kSlots] = {};     // this rank's packed tiles (segment padded to the largest rank's)
+    float* gathered[kSlots] = {};  // root: world segments
+    float* frame[kSlots] = {};     // root: the assembled W x H frame
+    unsigned long long* d_red = nullptr;  // 4 x 8 bytes for vr_mgpu_reduce
+};
+
+}  // namespace
+
+struct vr_mgpu {
+    int world = 1;
+    uint32_t W = 0, H = 0;
+    size_t seg_floats = 0;  // floats per rank segment = max tiles per rank * 64 * 64 * 4
+    std::vector<Rank> r;    // the ranks this process drives
+    unsigned long long frame_no = 0;
+    std::string err, backend;
+};
+
+namespace {
+
+int fail(vr_mgpu* m, int code, const std::string& msg)
+{
+    if (m) m->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define MG_HIP(m, call)                                                                                                \
+    do {                                                                                                               \
+        hipError_t e__ = (call);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return fail((m), e__ == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_HIP,                                     \
+                        std::string(#call) + " (vr_mgpu.cpp:" + std::to_string(__LINE__) + "): " + hipGetErrorString(e__)); \
+    } while (0)
+#define MG_NCCL(m, call)                                                                                               \
+    do {                                                                                                               \
+        ncclResult_t r__ = (call);                                                                                     \
+        if (r__ != ncclSuccess)                                                                                        \
+            return fail((m), VR_ERR_HIP, std::string(#call) + " (vr_mgpu.cpp:" + std::to_string(__LINE__) + "): " +     \
+                                             ncclGetErrorString(r__));                                                 \
+    } while (0)
+#define MG_VR(m, rk, call)                                                                                             \
+    do {                                                                                                               \
+        int rc__ = (call);                                                                                             \
+        if (rc__ != VR_OK) return fail((m), rc__, std::string(#call) + ": " + vr_last_error((rk).ctx));                \
+    } while (0)
+
+// streams, events and buffers of one rank (its device must be current)
+int setup_rank(vr_mgpu* m, Rank& k)
+{
+    MG_HIP(m, hipSetDevice(k.device));
+    for (int b = 0; b < kSlots; ++b) {
+        MG_HIP(m, hipStreamCreateWithFlags(&k.s_render[b], hipStreamNonBlocking));
+        MG_HIP(m, hipEventCreateWithFlags(&k.ev_render[b], hipEventDisableTiming));
+        MG_HIP(m, hipEventCreateWithFlags(&k.ev_done[b], hipEventDisableTiming));
+        MG_HIP(m, hipMalloc(&k.tiles[b], (m->seg_floats ? m->seg_floats : 4) * sizeof(float)));
+        MG_HIP(m, hipMemset(k.tiles[b], 0, (m->seg_floats ? m->seg_floats : 4) * sizeof(float)));
+        if (k.rank == 0) {
+            MG_HIP(m, hipMalloc(&k.gathered[b], (m->seg_floats ? m->seg_floats : 4) * (size_t)m->world * sizeof(float)));
+            MG_HIP(m, hipMalloc(&k.frame[b], (size_t)m->W * m->H * 4 * sizeof(float)));
+            MG_HIP(m, hipMemset(k.frame[b], 0, (size_t)m->W * m->H * 4 * sizeof(float)));
+        }
+    }
+    MG_HIP(m, hipStreamCreateWithFlags(&k.s_comm, hipStreamNonBlocking));
+    MG_HIP(m, hipMalloc(&k.d_red, 4 * sizeof(unsigned long long)));
+    MG_HIP(m, hipDeviceSynchronize());
+    return VR_OK;
+}
+
+void describe_backend(vr_mgpu* m)
+{
+    int v = 0;
+    (void)ncclGetVersion(&v);
+    m->backend = "RCCL " + std::to_string(v / 10000) + "." + std::to_string((v / 100) % 100) + "." + std::to_string(v % 100) +
+                 " ncclGather over xGMI, root = rank 0";
+}
+
+}  // namespace
+
+extern "C" {
+
+int vr_mgpu_unique_id(void* id128)
+{
+    if (!id128) return VR_ERR_INVALID_ARG;
+    static_assert(sizeof(ncclUniqueId) == VR_MGPU_ID_BYTES, "id size");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, VR_ERR_HIP, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    std::memcpy(id128, &id, sizeof id);
+    return VR_OK;
+}
+
+const char* vr_mgpu_last_error(const vr_mgpu* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+int vr_mgpu_create(vr_mgpu** out, vr_ctx* ctx, int rank, int world, const void* id128)
+{
+    if (!out) return fail(nullptr, VR_ERR_INVALID_ARG, "vr_mgpu_create: out is NULL");
+    *out = nullptr;
+    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return fail(nullptr, VR_ERR_INVALID_ARG, "vr_mgpu_create: bad arguments");
+    vr_mgpu* m = new (std::nothrow) vr_mgpu();
+    if (!m) return fail(nullptr, VR_ERR_OOM, "vr_mgpu_create: out of host memory");
+    auto bail = [&](int code) {
+        g_create_error = m->err;
+        vr_mgpu_destroy(m);
+        return code;
+    };
+    m->world = world;
+    int dev = 0;
+    if (vr_viewport(ctx, &m->W, &m->H, &dev) != VR_OK) return bail(fail(m, VR_ERR_INVALID_ARG, "vr_mgpu_create: bad context"));
+    m->seg_floats = (size_t)vr_tile_count(ctx, 0, world) * kTilePx * kTilePx * 4;
+    m->r.resize(1);
+    Rank& k = m->r[0];
+    k.device = dev;
+    k.rank = rank;
+    k.ctx = ctx;
+    int rc = setup_rank(m, k);
+    if (rc != VR_OK) return bail(rc);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    ncclResult_t nr = ncclCommInitRank(&k.comm, world, id, rank);
+    if (nr != ncclSuccess) return bail(fail(m, VR_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(nr)));
+    describe_backend(m);
+    *out = m;
+    return VR_OK;
+}
+
+int vr_mgpu_create_local(vr_mgpu** out, uint32_t width, uint32_t height, const int* device_ids, int n_devices)
+{
+    if (!out) return fail(nullptr, VR_ERR_INVALID_ARG, "vr_mgpu_create_local: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1) return fail(nullptr, VR_ERR_INVALID_ARG, "vr_mgpu_create_local: bad arguments");
+    vr_mgpu* m = new (std::nothrow) vr_mgpu();
+    if (!m) return fail(nullptr, VR_ERR_OOM, "vr_mgpu_create_local: out of host memory");
+    auto bail = [&](int code) {
+        g_create_error = m->err;
+        vr_mgpu_destroy(m);
+        return code;
+    };
+    m->world = n_devices;
+    m->W = width;
+    m->H = height;
+    m->r.resize((size_t)n_devices);
+    for (int i = 0; i < n_devices; ++i) {
+        Rank& k = m->r[(size_t)i];
+        k.device = device_ids[i];
+        k.rank = i;
+        k.own_ctx = true;
+        if (vr_create(&k.ctx, width, height, device_ids[i]) != VR_OK) {
+            k.ctx = nullptr;
+            return bail(fail(m, VR_ERR_HIP, std::string("vr_create on device ") + std::to_string(device_ids[i]) + ": " + vr_last_error(nullptr)));
+        }
+    }
+    m->seg_floats = (size_t)vr_tile_count(m->r[0].ctx, 0, n_devices) * kTilePx * kTilePx * 4;
+    for (auto& k : m->r) {
+        int rc = setup_rank(m, k);
+        if (rc != VR_OK) return bail(rc);
+    }
+    std::vector<ncclComm_t> comms((size_t)n_devices);
+    ncclResult_t nr = ncclCommInitAll(comms.data(), n_devices, device_ids);
+    if (nr != ncclSuccess) return bail(fail(m, VR_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(nr)));
+    for (int i = 0; i < n_devices; ++i) m->r[(size_t)i].comm = comms[(size_t)i];
+    describe_backend(m);
+    *out = m;
+    return VR_OK;
+}
+
+void vr_mgpu_destroy(vr_mgpu* m)
+{
+    if (!m) return;
+    for (auto& k : m->r) {
+        if (!k.ctx) continue;  // never set up (vr_create failed for it): nothing to release, and its device id may be invalid
+        (void)hipSetDevice(k.device);
+        (void)hipDeviceSynchronize();
+        if (k.comm) (void)ncclCommDestroy(k.comm);
+        for (int b = 0; b < kSlots; ++b) {
+            if (k.s_render[b]) (void)hipStreamDestroy(k.s_render[b]);
+            if (k.ev_render[b]) (void)hipEventDestroy(k.ev_render[b]);
+            if (k.ev_done[b]) (void)hipEventDestroy(k.ev_done[b]);
+            if (k.tiles[b]) (void)hipFree(k.tiles[b]);
+            if (k.gathered[b]) (void)hipFree(k.gathered[b]);
+            if (k.frame[b]) (void)hipFree(k.frame[b]);
+        }
+        if (k.s_comm) (void)hipStreamDestroy(k.s_comm);
+        if (k.d_red) (void)hipFree(k.d_red);
+        if (k.own_ctx && k.ctx) vr_destroy(k.ctx);
+    }
+    delete m;
+}
+
+int vr_mgpu_world(const vr_mgpu* m) { return m ? m->world : VR_ERR_INVALID_ARG; }
+int vr_mgpu_local_ranks(const vr_mgpu* m) { return m ? (int)m->r.size() : VR_ERR_INVALID_ARG; }
+vr_ctx* vr_mgpu_context(vr_mgpu* m, int local_rank)
+{
+    return (m && local_rank >= 0 && local_rank < (int)m->r.size()) ? m->r[(size_t)local_rank].ctx : nullptr;
+}
+const char* vr_mgpu_backend(const vr_mgpu* m) { return m ? m->backend.c_str() : ""; }
+
+int vr_mgpu_frame_async(vr_mgpu* m, int variant)
+{
+    if (!m) return VR_ERR_INVALID_ARG;
+    const int b = (int)(m->frame_no % kSlots);
+    // 1. every local rank renders its tiles into buffer set b (behind the gather that last read that buffer)
+    for (auto& k : m->r) {
+        MG_HIP(m, hipSetDevice(k.device));
+        if (k.used[b]) MG_HIP(m, hipStreamWaitEvent(k.s_render[b], k.ev_done[b], 0));
+        MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, m->world, k.tiles[b], k.s_render[b]));
+        MG_HIP(m, hipEventRecord(k.ev_render[b], k.s_render[b]));
+        MG_HIP(m, hipStreamWaitEvent(k.s_comm, k.ev_render[b], 0));
+    }
+    // 2. one gather: rank r's segment lands at gathered[b] + r * seg on the root.  Every rank's communication stream
+    //    carries the frames in the same order, so the collectives match up across ranks.
+    const size_t seg = m->seg_floats ? m->seg_floats : 4;
+    if (m->r.size() > 1) MG_NCCL(m, ncclGroupStart());
+    for (auto& k : m->r) {
+        MG_HIP(m, hipSetDevice(k.device));
+        MG_NCCL(m, ncclGather(k.tiles[b], k.rank == 0 ? k.gathered[b] : nullptr, seg, ncclFloat, 0, k.comm, k.s_comm));
+    }
+    if (m->r.size() > 1) MG_NCCL(m, ncclGroupEnd());
+    // 3. the root scatters the segments into the frame; the buffer set is free again when that is done
+    for (auto& k : m->r) {
+        MG_HIP(m, hipSetDevice(k.device));
+        if (k.rank == 0) MG_VR(m, k, vr_unpack_tiles_async(k.ctx, k.gathered[b], m->world, k.frame[b], k.s_comm));
+        MG_HIP(m, hipEventRecord(k.ev_done[b], k.s_comm));
+        k.used[b] = true;
+    }
+    ++m->frame_no;
+    return b;
+}
+
+int vr_mgpu_wait(vr_mgpu* m)
+{
+    if (!m) return VR_ERR_INVALID_ARG;
+    for (auto& k : m->r) {
+        MG_HIP(m, hipSetDevice(k.device));
+        for (int b = 0; b < kSlots; ++b) MG_HIP(m, hipStreamSynchronize(k.s_render[b]));
+        MG_HIP(m, hipStreamSynchronize(k.s_comm));
+    }
+    return VR_OK;
+}
+
+void* vr_mgpu_frame_device_ptr(vr_mgpu* m, int which)
+{
+    if (!m || which < 0 || which >= kSlots) return nullptr;
+    for (auto& k : m->r)
+        if (k.rank == 0) return k.frame[which];
+    return nullptr;
+}
+
+int vr_mgpu_download(vr_mgpu* m, int which, float* frag_rgba)
+{
+    if (!m || !frag_rgba || which < 0 || which >= kSlots) return VR_ERR_INVALID_ARG;
+    int rc = vr_mgpu_wait(m);
+    if (rc != VR_OK) return rc;
+    for (auto& k : m->r)
+        if (k.rank == 0) {
+            MG_HIP(m, hipSetDevice(k.device));
+            MG_HIP(m, hipMemcpy(frag_rgba, k.frame[which], (size_t)m->W * m->H * 4 * sizeof(float), hipMemcpyDeviceToHost));
+            return VR_OK;
+        }
+    return fail(m, VR_ERR_NOT_READY, "vr_mgpu_download: this process does not drive the root rank");
+}
+
+int vr_mgpu_reduce(vr_mgpu* m, uint64_t counters_sum[3], double local_value, double* max_value)
+{
+    if (!m) return VR_ERR_INVALID_ARG;
+    int rc = vr_mgpu_wait(m);
+    if (rc != VR_OK) return rc;
+    for (auto& k : m->r) {
+        uint64_t c[3] = {0, 0, 0};
+        MG_VR(m, k, vr_last_counters(k.ctx, c));
+        unsigned long long h[4] = {c[0], c[1], c[2], 0};
+        std::memcpy(&h[3], &local_value, sizeof(double));
+        MG_HIP(m, hipSetDevice(k.device));
+        MG_HIP(m, hipMemcpy(k.d_red, h, sizeof h, hipMemcpyHostToDevice));
+    }
+    if (m->r.size() > 1) MG_NCCL(m, ncclGroupStart());
+    for (auto& k : m->r) {
+        MG_HIP(m, hipSetDevice(k.device));
+        MG_NCCL(m, ncclAllReduce(k.d_red, k.d_red, 3, ncclUint64, ncclSum, k.comm, k.s_comm));
+        MG_NCCL(m, ncclAllReduce(k.d_red + 3, k.d_red + 3, 1, ncclFloat64, ncclMax, k.comm, k.s_comm));
+    }
+    if (m->r.size() > 1) MG_NCCL(m, ncclGroupEnd());
+    Rank& k0 = m->r[0];
+    MG_HIP(m, hipSetDevice(k0.device));
+    MG_HIP(m, hipStreamSynchronize(k0.s_comm));
+    unsigned long long h[4];
+    MG_HIP(m, hipMemcpy(h, k0.d_red, sizeof h, hipMemcpyDeviceToHost));
+    for (auto& k : m->r) {
+        MG_HIP(m, hipSetDevice(k.device));
+        MG_HIP(m, hipStreamSynchronize(k.s_comm));
+    }
+    if (counters_sum) {
+        counters_sum[0] = h[0];
+        counters_sum[1] = h[1];
+        counters_sum[2] = h[2];
+    }
+    if (max_value) std::memcpy(max_value, &h[3], sizeof(double));
+    return VR_OK;
+}
+
+}  // extern "C"

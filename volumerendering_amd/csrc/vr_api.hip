@@ -32,6 +32,7 @@ struct KernelRing {  // one (start, stop) event pair per render call, reused rou
 }  // namespace
 
 constexpr int kInFlight = 4;  // renders that may be in flight at a time (one stream and one output buffer each)
+constexpr int kOrderRing = 8;  // launch-order buffers: written behind launch k, read by launches k+1 .. k+3 only
 
 struct vr_ctx {
     int device = 0;
@@ -43,7 +44,8 @@ struct vr_ctx {
     float* vol_dens[VR_MAX_VOLUMES] = {};     // scalar density plane of each slot (DevVolume::dens)
     size_t vol_dens_cap[VR_MAX_VOLUMES] = {};  // in voxels
     bool vol_grad_derived[VR_MAX_VOLUMES] = {};  // .rgb verified to be PreComputeGradient(false) of .a, bit for bit
-    int layout_mode = 0;                       // vr_set_volume_layout: 0 auto, 1 the reference's vec4 voxels only
+    int layout_mode = 0;                       // vr_set_volume_layout: 0 density plane for .a fetches, 1 vec4 voxels only,
+                                               // 2 plane + lit gradients derived on the fly
     float2* merged_bricks = nullptr;           // VOLUME_MASK: (CT density max, mask rgb max), rebuilt when stale
     bool merged_stale = true;
     unsigned char* brick_dist = nullptr;       // distance field over the records in use; key below says for what
@@ -72,6 +74,18 @@ struct vr_ctx {
     size_t block_counts_cap[kInFlight] = {};   // in blocks
     hipEvent_t slot_done[kInFlight] = {};      // recorded behind the launch that last used the slot (any stream)
     bool slot_used[kInFlight] = {};
+    // Longest-first launch order (MarchParams::order): behind every march launch one small kernel sorts that launch's
+    // blocks by their longest ray chain; a later launch of the same shape takes its blocks in that order.
+    struct OrderSlot {
+        unsigned* buf = nullptr;
+        size_t cap = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t sorted = nullptr;
+        unsigned long long key = 0, seq = 0;
+        bool valid = false;
+    } order_ring[kOrderRing];
+    unsigned long long order_seq = 0;
+    int order_mode = 1;  // 0 = launch the blocks in index order (VR_EXP_ORDER=0)
     unsigned launch_seq = 0;
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
@@ -291,6 +305,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             return fail(c, VR_ERR_NOT_READY, "vr_render: TF slot " + std::to_string(i) + " is empty");
     if (c->u.steps_count < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: negative steps_count");
     VR_HIP(c, hipSetDevice(c->device));
+    (void)hipGetLastError();  // a stale error of somebody else's call must not be reported as a failed launch below
 
     MarchParams P;
     std::memset(&P, 0, sizeof P);
@@ -315,7 +330,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     }
     for (int i = 0; i < VR_MAX_VOLUMES; ++i) {
         P.vol[i] = c->vol[i];
-        const bool plane = c->layout_mode == 0 && c->vol_dens[i] && c->vol[i].data;
+        const bool plane = c->layout_mode != 1 && c->vol_dens[i] && c->vol[i].data;
         P.vol[i].dens = plane ? c->vol_dens[i] : nullptr;
         P.vol[i].a_base = plane ? reinterpret_cast<const char*>(c->vol_dens[i]) : reinterpret_cast<const char*>(c->vol[i].data) + 12;
         P.vol[i].a_shift = plane ? 2 : 4;
@@ -443,7 +458,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const int dp = (fl == 7 || fl == 10) ? 4 : ((fl == 8 || fl == 11) ? 2 : 0);
         // gradients on the fly (one-lane kernel, lit shader): the volume's .rgb is verified to be the central difference of
         // its .a, so the eight corners are derived from the density plane -- same bits, a quarter of the footprint
-        const bool otf = variant == VR_VARIANT_LIGHT && c->layout_mode == 0 && c->vol_grad_derived[0] && P.vol[0].dens != nullptr &&
+        const bool otf = variant == VR_VARIANT_LIGHT && c->layout_mode == 2 && c->vol_grad_derived[0] && P.vol[0].dens != nullptr &&
                          !wtb && dp == 0;
         c->last_otf = otf;
         const bool dp_pipe = fl == 10 || fl == 11;  // ... with the next round's corner loads software-pipelined  // lanes per ray (vr_dp.h): 64 / 32 workgroups per tile
@@ -464,6 +479,23 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         P.block_counts = c->d_block_counts[cb];
         c->cnt_buf = cb;
+        // launch order: the most recent sort (at most three launches old, so its buffer cannot be recycled under this
+        // launch) of a launch of the same shape; same stream -> ordered by the stream, other stream -> by its event
+        const unsigned long long okey = ((unsigned long long)grid.x << 32) ^ ((unsigned long long)block.x << 20) ^
+                                        ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
+                                        ((unsigned long long)fl << 44) ^ (packed ? 1ull << 63 : 0ull);
+        P.order = nullptr;
+        if (c->order_mode == 1 && !wtb) {
+            const vr_ctx::OrderSlot* best = nullptr;
+            for (const auto& o : c->order_ring)
+                if (o.valid && o.key == okey && o.seq + 3 >= c->order_seq && (!best || (o.stream == s) > (best->stream == s) ||
+                                                                               ((o.stream == s) == (best->stream == s) && o.seq > best->seq)))
+                    best = &o;
+            if (best) {
+                if (best->stream != s) VR_HIP(c, hipStreamWaitEvent(s, best->sorted, 0));
+                P.order = best->buf;
+            }
+        }
         const int slot = (int)(c->ring.head % kRing);
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
         VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
@@ -515,6 +547,25 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
+        if (c->order_mode == 1 && !wtb) {
+            vr_ctx::OrderSlot& o = c->order_ring[c->order_seq % kOrderRing];
+            o.valid = false;
+            if (grid.x > o.cap) {
+                if (o.buf) (void)hipFree(o.buf);
+                o.buf = nullptr;
+                o.cap = 0;
+                VR_HIP(c, hipMalloc(&o.buf, (size_t)grid.x * sizeof(unsigned)));
+                o.cap = grid.x;
+            }
+            hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, s, c->d_block_counts[cb], (int)grid.x, o.buf);
+            VR_HIP(c, hipGetLastError());
+            VR_HIP(c, hipEventRecord(o.sorted, s));
+            o.stream = s;
+            o.key = okey;
+            o.seq = c->order_seq;
+            o.valid = true;
+        }
+        ++c->order_seq;
         VR_HIP(c, hipEventRecord(c->slot_done[cb], s));
         c->slot_used[cb] = true;
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
@@ -539,6 +590,7 @@ int fetch_counters(vr_ctx* c)
 {
     if (!c->cnt_pending) return VR_OK;
     VR_HIP(c, hipSetDevice(c->device));
+    (void)hipGetLastError();
     if (c->cnt_blocks > 0) {
         // the launch may have been enqueued on a stream of the caller's that no longer exists: wait for the event recorded
         // behind it (owned by the context; other launches in flight are not waited for), then use the context's own stream
@@ -559,6 +611,7 @@ int fetch_counters(vr_ctx* c)
 // per-brick density / rgb maxima for the exact empty-space test (one pass over the volume; after every change)
 int refresh_bricks(vr_ctx* c, int slot)
 {
+    (void)hipGetLastError();  // (see enqueue_render)
     const DevVolume& v = c->vol[slot];
     if (c->vol_bricks[slot]) (void)hipFree(c->vol_bricks[slot]);
     c->vol_bricks[slot] = nullptr;
@@ -604,6 +657,7 @@ int check_slot(vr_ctx* c, int slot, const char* who)
     if (!c->vol[slot].data) return fail(c, VR_ERR_NOT_READY, std::string(who) + ": volume slot is empty");
     VR_HIP(c, hipSetDevice(c->device));
     VR_HIP(c, hipDeviceSynchronize());  // asynchronous renders on the caller's streams may still read the slot
+    (void)hipGetLastError();
     return VR_OK;
 }
 
@@ -618,6 +672,7 @@ int upload_raw(vr_ctx* c, int slot, const T* raw, uint16_t nx, uint16_t ny, uint
     if (n > 0xFFFFFFFFull) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_upload_raw: more than 2^32 voxels");
     VR_HIP(c, hipSetDevice(c->device));
     VR_HIP(c, hipDeviceSynchronize());  // asynchronous renders on the caller's streams may still read the slot
+    (void)hipGetLastError();
     const size_t bytes = n * sizeof(float4);
     if (c->vol[slot].data && c->vol_bytes[slot] != bytes) {
         (void)hipFree(const_cast<float4*>(c->vol[slot].data));
@@ -767,6 +822,9 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
             return bail(VR_ERR_HIP);
     for (int i = 0; i < kInFlight; ++i)
         if (!hip_ok(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming), "hipEventCreate")) return bail(VR_ERR_HIP);
+    for (auto& o : c->order_ring)
+        if (!hip_ok(hipEventCreateWithFlags(&o.sorted, hipEventDisableTiming), "hipEventCreate")) return bail(VR_ERR_HIP);
+    if (const char* e = getenv("VR_EXP_ORDER")) c->order_mode = atoi(e);
     if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 3 * sizeof(unsigned long long), hipHostMallocDefault),
                 "hipHostMalloc"))
@@ -820,6 +878,10 @@ void vr_destroy(vr_ctx* c)
     }
     for (auto e : c->slot_done)
         if (e) (void)hipEventDestroy(e);
+    for (auto& o : c->order_ring) {
+        if (o.sorted) (void)hipEventDestroy(o.sorted);
+        if (o.buf) (void)hipFree(o.buf);
+    }
     if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
     if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);
     if (c->tm.ev_k1) (void)hipEventDestroy(c->tm.ev_k1);
@@ -987,6 +1049,7 @@ int vr_unpack_tiles_async(vr_ctx* c, const void* d_gathered, int world, void* d_
     if (!c) return VR_ERR_INVALID_ARG;
     if (!d_gathered || world < 1) return fail(c, VR_ERR_INVALID_ARG, "vr_unpack_tiles_async: bad arguments");
     VR_HIP(c, hipSetDevice(c->device));
+    (void)hipGetLastError();
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     float4* frame = d_frame ? (float4*)d_frame : c->d_frame;
     int tpr = tile_count(c, 0, world);
@@ -1005,6 +1068,7 @@ int vr_download(vr_ctx* c, float* frag_rgba, uint8_t* present_bgra8, uint64_t* c
     size_t n = (size_t)c->W * c->H;
     if (frag_rgba) VR_HIP(c, hipMemcpy(frag_rgba, c->d_frame, n * sizeof(float4), hipMemcpyDeviceToHost));
     if (present_bgra8) {
+        (void)hipGetLastError();
         hipLaunchKernelGGL(present_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_frame,
                            c->d_present, (int)n);
         VR_HIP(c, hipGetLastError());
@@ -1073,6 +1137,15 @@ int vr_reset_kernel_times(vr_ctx* c)
 
 void* vr_frame_device_ptr(vr_ctx* c) { return c ? (void*)c->d_frame : nullptr; }
 
+int vr_viewport(const vr_ctx* c, uint32_t* width, uint32_t* height, int* device_id)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (width) *width = c->W;
+    if (height) *height = c->H;
+    if (device_id) *device_id = c->device;
+    return VR_OK;
+}
+
 int vr_last_covered_pixels(vr_ctx* c, uint64_t* covered)
 {
     if (!c || !covered) return VR_ERR_INVALID_ARG;
@@ -1118,7 +1191,7 @@ int vr_last_kernel_flavour(vr_ctx* c)
 int vr_set_volume_layout(vr_ctx* c, int mode)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (mode < 0 || mode > 1) return fail(c, VR_ERR_INVALID_ARG, "vr_set_volume_layout: unknown mode");
+    if (mode < 0 || mode > 2) return fail(c, VR_ERR_INVALID_ARG, "vr_set_volume_layout: unknown mode");
     c->layout_mode = mode;
     return VR_OK;
 }

@@ -68,6 +68,10 @@ struct MarchParams {
     int bnx, bny, bnz;       // bricks per axis
     float bsx, bsy, bsz;     // n/8 per axis of vol[skip_vol] (exact in f32)
     int tf_zero_prefix;      // largest Z with opacity[0..Z] == 0 exactly (-1: none)
+    // Launch order of the logical blocks: workgroup blockIdx.x works on logical block order[blockIdx.x] (nullptr =
+    // identity).  The host sorts the blocks of the previous frame by their longest ray chain, longest first, so that the
+    // long blocks start at once and the short ones fill the machine at the end (speed only: a permutation of the blocks).
+    const unsigned* order;
     float4* out;
     unsigned long long* block_counts;  // [gridDim.x][kBlockRecord]: composited, covered, fetched, t0, t1, hw id
 };

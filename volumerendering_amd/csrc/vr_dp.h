@@ -40,8 +40,9 @@ __device__ __forceinline__ PixelSlot map_pixel_dp(const MarchParams& P)
 {
     PixelSlot s;
     constexpr int kBpt = (K == 4) ? 64 : 32;  // workgroups per tile
-    const int n = blockIdx.x / kBpt;          // ordinal of the owned tile this block works on
-    const int sub = blockIdx.x % kBpt;
+    const int lb = logical_block(P);
+    const int n = lb / kBpt;          // ordinal of the owned tile this block works on
+    const int sub = lb % kBpt;
     const bool in_launch = n < P.n_tiles;
     const int t = P.rank + n * P.world;
     const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;

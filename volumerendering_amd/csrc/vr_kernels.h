@@ -780,22 +780,30 @@ struct PixelSlot {
     bool in_launch;  // the block's tile exists (the grid is padded to 8 x 16 blocks)
 };
 
+// the logical block this workgroup works on (wave-uniform; P.order is a permutation of [0, gridDim.x))
+__device__ __forceinline__ int logical_block(const MarchParams& P)
+{
+    if (P.order == nullptr) return (int)blockIdx.x;
+    return (int)__builtin_amdgcn_readfirstlane((int)P.order[blockIdx.x]);
+}
+
 __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
 {
     PixelSlot s;
+    const int lb = logical_block(P);
     // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD; speed only, never
     // correctness).  The 16 blocks of one 64x64 tile stay on ONE XCD (their rays traverse neighbouring voxels:
     // shared L2 lines), while consecutive tiles go to different XCDs so that every XCD gets an even share of the
     // heavy (volume-covered) and the empty parts of the screen.
     // A block is 1 or 4 wavefronts (blockDim.x 64 / 256); a tile is 64 packets of 8x8 pixels either way, packet
     // pk = 4 * (16x16 sub-block) + quadrant.
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xcd = lb & 7, q = lb >> 3;
     const int wpb = blockDim.x >> 6, bpt = 64 / wpb;  // wavefronts per block, blocks per tile
     int n = xcd + 8 * (q / bpt);  // ordinal of the owned tile this block works on
     int pk = (q % bpt) * wpb + (threadIdx.x >> 6);
     if (P.xcd_mode == 1) {  // consecutive blocks of a tile on consecutive XCDs: every XCD gets an even sample of the screen
-        n = blockIdx.x / bpt;
-        pk = (blockIdx.x % bpt) * wpb + (threadIdx.x >> 6);
+        n = lb / bpt;
+        pk = (lb % bpt) * wpb + (threadIdx.x >> 6);
     }
     const int sub = pk >> 2;
     const bool in_launch = n < P.n_tiles;
@@ -890,7 +898,7 @@ __device__ __forceinline__ void store_block_counts(const MarchParams& P, unsigne
             fc += part[i][1];
             cr = part[i][2] > cr ? part[i][2] : cr;
         }
-        unsigned long long* o = P.block_counts + (size_t)blockIdx.x * kBlockRecord;
+        unsigned long long* o = P.block_counts + (size_t)logical_block(P) * kBlockRecord;  // records are per LOGICAL block
         o[0] = pc & ((1ull << 40) - 1);
         o[1] = pc >> 40;
         o[2] = fc;
@@ -1326,6 +1334,37 @@ __global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned lo
     }
     __syncthreads();
     if (threadIdx.x < 3) out[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+// One workgroup: order[] = the logical blocks of the launch whose records are `in`, sorted by the longest per-ray sample
+// chain of the block (record word 5, bits 40..), longest first -- a counting sort over 1024 key buckets.  The next
+// frame's workgroups take their blocks in this order (MarchParams::order): longest-processing-time-first scheduling.
+__global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long long* __restrict__ in, int n_blocks,
+                                                            unsigned* __restrict__ order)
+{
+    __shared__ unsigned hist[1024];
+    __shared__ unsigned base[1024];
+    const int t = threadIdx.x;
+    hist[t] = 0;
+    __syncthreads();
+    // bucket 0 = the longest chains; chains beyond 1023 * 4 share bucket 0
+    auto bucket = [&](int b) {
+        const unsigned long long crit = in[(size_t)b * kBlockRecord + 5] >> 40;
+        const unsigned k = (unsigned)(crit >> 2);
+        return 1023u - (k > 1023u ? 1023u : k);
+    };
+    for (int b = t; b < n_blocks; b += 1024) atomicAdd(&hist[bucket(b)], 1u);
+    __syncthreads();
+    if (t == 0) {
+        unsigned acc = 0;
+        for (int k = 0; k < 1024; ++k) {
+            base[k] = acc;
+            acc += hist[k];
+        }
+    }
+    __syncthreads();
+    // scatter with one cursor per bucket (the order inside a bucket does not matter)
+    for (int b = t; b < n_blocks; b += 1024) order[atomicAdd(&base[bucket(b)], 1u)] = (unsigned)b;
 }
 
 // ---- brick distance field (rebuilt when the volume or the opacity table changes) --------------------------------
