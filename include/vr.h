@@ -256,6 +256,18 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *      the default uses for small launches)                                                                  */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 
+/* Arithmetic mode.  WGSL leaves it to the implementation whether `a * b + c` is evaluated with one rounding or two
+ * (the reference's Tint -> HLSL -> D3D12 back end emits `mad`).
+ *   VR_ARITH_SEPARATE (default)  product and sum are rounded separately everywhere: bit-exact with the oracle's default mode
+ *   VR_ARITH_FUSED               the per-sample expressions of that shape -- texture coordinates p * N - 0.5, every
+ *                                linear-filter lerp a + (b - a) * t, dot products, light.diffuse * m * kD + light.ambient * kA,
+ *                                the CT / RT colour mix and FrontToBackBlend -- are single fused multiply-adds: bit-exact with
+ *                                the oracle's fused mode, about a fifth fewer vector instructions per sample.  Ray placement
+ *                                (matrices, slab test, step vectors, p += step) is identical in both modes.             */
+#define VR_ARITH_SEPARATE 0
+#define VR_ARITH_FUSED 1
+int vr_set_arithmetic(vr_ctx* ctx, int mode);
+
 /* Volume layout in HBM (A/B measurements; frames and counts are bit-identical in every mode).
  *   0  default: next to the reference's vec4 voxels every slot keeps a scalar f32 density plane (4 B / voxel); fetches
  *      that consume .a alone (BasicVolumeApp.wgsl:171 and the density / dose fetches of the other shaders) read it

@@ -63,6 +63,9 @@ def load() -> C.CDLL:
     lib.vro_jitter.restype = C.c_float
     lib.vro_pow.argtypes = [C.c_float, C.c_float]
     lib.vro_pow.restype = C.c_float
+    lib.vro_set_arithmetic.argtypes = [C.c_int]
+    lib.vro_set_arithmetic.restype = None
+    lib.vro_get_arithmetic.restype = C.c_int
     _lib = lib
     return lib
 
@@ -164,6 +167,28 @@ def lerp_vec4(x0, x1, fx0, fx1):
 
 def jitter(x, y):
     return float(load().vro_jitter(x, y))
+
+
+SEPARATE, FUSED = 0, 1
+
+
+def set_arithmetic(mode: int):
+    """0 = product and sum of every a*b+c rounded separately (default); 1 = the per-sample ones fused (vr_oracle.c header)."""
+    load().vro_set_arithmetic(int(mode))
+
+
+class arithmetic:
+    """with ob.arithmetic(ob.FUSED): ...  -- restores the previous mode on exit."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = int(load().vro_get_arithmetic())
+        set_arithmetic(self.mode)
+
+    def __exit__(self, *a):
+        set_arithmetic(self.prev)
 
 
 def pow_rep(x, y):

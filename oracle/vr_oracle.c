@@ -20,9 +20,33 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* ------------------------------------------------------------------ arithmetic modes
+ * WGSL leaves it to the implementation whether `a * b + c` is evaluated with one rounding (fused multiply-add) or two;
+ * the reference's back end (Tint -> HLSL -> D3D12 driver) emits `mad` for these expressions.  Mode 0 (default,
+ * "separate") rounds the product and the sum separately everywhere.  Mode 1 ("fused") evaluates the PER-SAMPLE
+ * expressions of that shape with fmaf -- texture coordinates p * N - 0.5, every linear-filter lerp a + (b - a) * t,
+ * dot products (x*x' first, then fma, fma), light.diffuse * m * kD + light.ambient * kA, the CT / RT colour mix and
+ * FrontToBackBlend's (1 - dst.a) * src + dst.  Everything that places the ray (matrix products, slab test, SetupRay,
+ * step vectors, jitter, the repeated additions p += step) is the same in both modes, so both march the same positions. */
+static int g_fused = 0;
+void vro_set_arithmetic(int fused) { g_fused = fused ? 1 : 0; }
+int vro_get_arithmetic(void) { return g_fused; }
+static float mad(float a, float b, float c) { return g_fused ? fmaf(a, b, c) : a * b + c; }
+
 /* ------------------------------------------------------------------ small vector helpers */
 
-static float dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+/* ray placement (both modes): separately rounded */
+static float dot3s(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static float length3s(const float a[3]) { return sqrtf(dot3s(a, a)); }
+static void normalize3s(const float a[3], float out[3])
+{
+    float inv = 1.0f / length3s(a);
+    out[0] = a[0] * inv;
+    out[1] = a[1] * inv;
+    out[2] = a[2] * inv;
+}
+/* per sample (mode dependent) */
+static float dot3(const float a[3], const float b[3]) { return mad(a[2], b[2], mad(a[1], b[1], a[0] * b[0])); }
 static float length3(const float a[3]) { return sqrtf(dot3(a, a)); }
 static void normalize3(const float a[3], float out[3])
 {
@@ -32,7 +56,7 @@ static void normalize3(const float a[3], float out[3])
     out[2] = a[2] * inv;
 }
 static float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
-static float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+static float lerpf(float a, float b, float t) { return mad(b - a, t, a); }
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 /* f32 -> i32 conversion is SATURATING with NaN -> 0 (WGSL clamps the value to the target range; C leaves the
  * out-of-range case undefined).  Only reachable with non-finite voxel data. */
@@ -176,9 +200,9 @@ float vro_pow(float x, float y)
  * (VolumeFile.cpp:306). */
 static void tex3_linear(const vro_volume* v, const float p[3], float out[4])
 {
-    float x = p[0] * (float)v->nx - 0.5f;
-    float y = p[1] * (float)v->ny - 0.5f;
-    float z = p[2] * (float)v->nz - 0.5f;
+    float x = mad(p[0], (float)v->nx, -0.5f);
+    float y = mad(p[1], (float)v->ny, -0.5f);
+    float z = mad(p[2], (float)v->nz, -0.5f);
     float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
     float fx = x - x0, fy = y - y0, fz = z - z0;
     int i0, i1, j0, j1, k0, k1;
@@ -219,7 +243,7 @@ static void tex3_nearest(const vro_volume* v, const float p[3], float out[4])
 /* 1-D linear lookups of the transfer-function textures at coordinate d */
 static void tf_coords(int res, float d, int* i0, int* i1, float* f)
 {
-    float x = d * (float)res - 0.5f;
+    float x = mad(d, (float)res, -0.5f);
     float x0 = floorf(x);
     *f = x - x0;
     texel_pair(x0, res, i0, i1);
@@ -274,8 +298,8 @@ int vro_setup_ray(const vro_uniforms* u, int W, int H, int px, int py, float sta
     unproject(u, ndcx, ndcy, 0.0f, O);
     unproject(u, ndcx, ndcy, 1.0f, F);
     D[0] = F[0] - O[0]; D[1] = F[1] - O[1]; D[2] = F[2] - O[2];
-    float seg = length3(D);
-    normalize3(D, d);
+    float seg = length3s(D);
+    normalize3s(D, d);
 
     float t0 = -INFINITY, t1 = INFINITY;
     int a0 = -1, a1 = -1;
@@ -325,10 +349,10 @@ static void front_to_back_blend(const float rgb[3], float a, float dst[4])
 {
     float sr = rgb[0] * a, sg = rgb[1] * a, sb = rgb[2] * a, sa = a;
     float om = 1.0f - dst[3];
-    dst[0] = om * sr + dst[0];
-    dst[1] = om * sg + dst[1];
-    dst[2] = om * sb + dst[2];
-    dst[3] = om * sa + dst[3];
+    dst[0] = mad(om, sr, dst[0]);
+    dst[1] = mad(om, sg, dst[1]);
+    dst[2] = mad(om, sb, dst[2]);
+    dst[3] = mad(om, sa, dst[3]);
 }
 
 /* light.diffuse * max(dot(N,L),0) * kD + light.ambient * kA, L = normalize(lightPos - w) */
@@ -339,7 +363,7 @@ static void shade(const float N[3], const float w[3], const float lpos[3], const
     float L[3];
     normalize3(lv, L);
     float m = max0(dot3(N, L));
-    for (int c = 0; c < 3; ++c) out[c] = (diffuse[c] * m) * kD + ambient[c] * kA;
+    for (int c = 0; c < 3; ++c) out[c] = mad(diffuse[c] * m, kD, ambient[c] * kA);
 }
 
 /* ------------------------------------------------------------------ fs_main */
@@ -358,8 +382,8 @@ uint32_t vro_shade_pixel(int variant, const vro_uniforms* u, const vro_volume* v
     /* SetupRay  BasicVolumeApp.wgsl:86-96 */
     float diff[3] = { end[0] - start[0], end[1] - start[1], end[2] - start[2] };
     float dir[3];
-    normalize3(diff, dir);
-    float ray_len = length3(diff);
+    normalize3s(diff, dir);
+    float ray_len = length3s(diff);
 
     switch (u->fragment_mode) { /* BasicVolumeApp.wgsl:128-143 */
     case 1: out[0] = fabsf(dir[0]); out[1] = fabsf(dir[1]); out[2] = fabsf(dir[2]); out[3] = 1.0f; return 0;
@@ -495,7 +519,7 @@ uint32_t vro_shade_pixel(int variant, const vro_uniforms* u, const vro_volume* v
             float o_rt = tf_opacity(&tfs[1], rt[3]);
             tf_color(&tfs[1], rt[3], crt);
             if (in_sample_coords(u, p) && dst[3] < 1.0f) {
-                for (int c = 0; c < 3; ++c) col[c] = cct[c] * (1.0f - o_rt) + crt[c] * o_rt;
+                for (int c = 0; c < 3; ++c) col[c] = mad(crt[c], o_rt, cct[c] * (1.0f - o_rt));
                 front_to_back_blend(col, o_ct, dst);
                 ++blends;
             }
@@ -511,7 +535,7 @@ uint32_t vro_shade_pixel(int variant, const vro_uniforms* u, const vro_volume* v
             if (in_sample_coords(u, p) && dst[3] <= 0.95f) {
                 static const float lp[3] = { 0.0f, -5.0f, 0.0f };
                 float N[3], s[3];
-                for (int c = 0; c < 3; ++c) col[c] = cct[c] * (1.0f - o_rt) + crt[c] * o_rt;
+                for (int c = 0; c < 3; ++c) col[c] = mad(crt[c], o_rt, cct[c] * (1.0f - o_rt));
                 normalize3(ct, N);
                 shade(N, wc, lp, ldif, lamb, 3.5f, 0.5f, s); /* BlinnPhong :129-139 */
                 col[0] *= s[0]; col[1] *= s[1]; col[2] *= s[2];
@@ -531,7 +555,7 @@ uint32_t vro_shade_pixel(int variant, const vro_uniforms* u, const vro_volume* v
             if (in_sample_coords(u, p) && dst[3] <= 0.95f) {
                 static const float lp[3] = { 0.0f, -5.0f, 0.0f };
                 float N[3], s3[3];
-                for (int c = 0; c < 3; ++c) col[c] = cct[c] * (1.0f - o_rt) + crt[c] * o_rt;
+                for (int c = 0; c < 3; ++c) col[c] = mad(crt[c], o_rt, cct[c] * (1.0f - o_rt));
                 normalize3(ct, N);
                 shade(N, wc, lp, ldif, lamb, 3.5f, 0.5f, s3); /* BlinnPhong :132-143 */
                 col[0] *= s3[0]; col[1] *= s3[1]; col[2] *= s3[2];

@@ -65,6 +65,11 @@ void vro_lerp_float(int x0, int x1, float fx0, float fx1, float* out);
 void vro_lerp_vec4(int x0, int x1, const float fx0[4], const float fx1[4], float* out);
 
 /* jitter() helper exposed for tests. */
+/* Arithmetic mode (see vr_oracle.c): 0 = every a*b+c rounds product and sum separately (default), 1 = the per-sample
+ * expressions of that shape are fused multiply-adds.  Process-wide; set it before rendering. */
+void vro_set_arithmetic(int fused);
+int vro_get_arithmetic(void);
+
 float vro_jitter(float x, float y);
 /* WGSL pow(x, y) = exp2(y * log2(x)) (what the reference's HLSL back end emits), evaluated through f64 with a fixed
  * operation sequence so that the kernel can reproduce it bit for bit; x < 0 -> NaN, pow(0, 0) -> NaN. */

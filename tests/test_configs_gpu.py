@@ -157,3 +157,28 @@ def test_c5_16gib_volume_64bit_addressing_vs_oracle():
         got = frag[pxy[:, 1], pxy[:, 0]]
         assert np.array_equal(vt.bits(got), vt.bits(out))
         assert float(np.max(np.abs(got - out))) <= 1e-4
+
+
+@pytest.mark.parametrize("workload", ["C1", "C2", "C3", "C4"])
+def test_config_fused_arithmetic_vs_fused_oracle_and_vs_default(workload):
+    """vr_set_arithmetic(VR_ARITH_FUSED) at full size: bit-exact against the oracle's fused mode; against the default
+    (separately rounded) GPU frame the difference stays within BASELINE.json's 1e-4 except where one of the shader's hard
+    thresholds (opacity cut-off, IsInSampleCoords) lands on the other side of a rounding -- those pixels are counted and
+    must be rare (they are the reference's own discontinuities, not an error of either mode)."""
+    n, W, H, vname = wl.WORKLOADS[workload]
+    with host.Application(W, H, 0) as app:
+        variant, vols = wl.build_scene(app, workload, "default", quiet=True)
+        ctx = app.context()
+        sep, n_sep, cov_sep, _ = gpu_frame(app)
+        ctx.set_arithmetic(capi.ARITH_FUSED)
+        fus, n_fus, cov_fus, fetched = gpu_frame(app)
+        with ob.arithmetic(ob.FUSED):
+            ref, n_ref, cov_ref = oracle_frame(app, variant, vols, W, H)
+        assert_frame_equal(fus, ref, (workload, "fused"))
+        assert (n_fus, cov_fus) == (n_ref, cov_ref) and cov_fus == cov_sep
+        d = np.max(np.abs(fus - sep), axis=2)
+        over = int((d > 1e-4).sum())
+        print(f"{workload}: fused vs separate max abs {d.max():.3e}, pixels over 1e-4: {over} of {cov_sep}, "
+              f"composited samples {n_fus} vs {n_sep}")
+        assert over <= 1e-3 * cov_sep
+        assert abs(n_fus - n_sep) <= 1e-4 * n_sep

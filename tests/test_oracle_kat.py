@@ -279,3 +279,52 @@ def test_in_shader_gradient_known_answers():
         uu.light_pos[0], uu.light_pos[1], uu.light_pos[2] = x, 0.0, 0.0
         return ob.render(ob.LIGHT_INSHADER, uu, [ramp], [tf2], W, H)[0]
     assert with_light(-5.0)[..., 0].sum() > 1.5 * with_light(5.0)[..., 0].sum()
+
+
+def test_fused_arithmetic_mode_known_answers():
+    """vro_set_arithmetic(1): the per-sample a*b+c are single fused multiply-adds.  Pins: (1) an exactly representable case
+    where fusing cannot matter is bit-identical in both modes, (2) a case built so that the product's rounding error is
+    visible differs exactly as fmaf predicts, (3) ray placement (debug modes, covered pixels, sample counts of a thin
+    medium) is identical in both modes, (4) on an ordinary scene the two modes agree to <= 1e-4."""
+    n, res = 8, 16
+    u = hr.make_uniforms(W, H, steps_count=20, step_size=1 / 8)
+    # (1) opacity 0.5, colour 0.5, constant density 0.5: every product and sum is exact in binary
+    tf = const_tf(res, 0.5, (0.5, 0.5, 0.5))
+    v = const_volume(n, 0.5)
+    a, na, _ = ob.render(ob.BASIC, u, [v], [tf], W, H)
+    with ob.arithmetic(ob.FUSED):
+        b, nb, _ = ob.render(ob.BASIC, u, [v], [tf], W, H)
+    assert na == nb > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # (2) one blend of (rgb, alpha) = (c, o) into an empty dst: separate = fl(fl(c*o) * 1 + 0), fused = fma(1, fl(c*o), 0):
+    # equal; the second blend is (1 - o) * fl(c*o) + fl(c*o): the product's rounding error survives only when fused
+    c, o = f32(0.7), f32(0.3)
+    tf2 = const_tf(res, float(o), (float(c), float(c), float(c)))
+    u2 = hr.make_uniforms(W, H, steps_count=2, step_size=1 / 8)
+    s, _, _ = ob.render(ob.BASIC, u2, [v], [tf2], W, H)
+    with ob.arithmetic(ob.FUSED):
+        f, _, _ = ob.render(ob.BASIC, u2, [v], [tf2], W, H)
+    src = f32(c * o)
+    om = f32(f32(1) - o)
+    sep = f32(f32(om * src) + src)
+    fus = f32(math.fma(float(om), float(src), float(src))) if hasattr(math, "fma") else f32(np.float64(om) * np.float64(src) + np.float64(src))
+    two = (s[..., 3] > o)  # pixels whose ray took both steps inside the box
+    assert two.any() and np.all(s[two][:, 0] == sep) and np.all(f[two][:, 0] == fus)
+    # (3) ray placement does not depend on the mode
+    for mode in (1, 2, 3, 4):
+        um = hr.make_uniforms(W, H, fragment_mode=mode)
+        x, _, cx = ob.render(ob.LIGHT, um, [v], [tf], W, H)
+        with ob.arithmetic(ob.FUSED):
+            y, _, cy = ob.render(ob.LIGHT, um, [v], [tf], W, H)
+        assert cx == cy and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    # (4) ordinary scenes: the modes agree to the tolerance BASELINE.json states (and do differ in some bits)
+    import vrtest as vt
+    from volumerendering_amd import capi
+    for variant in (capi.BASIC, capi.LIGHT, capi.VOLUME_MASK, capi.MULTI_CTRT):
+        vols, tfs = vt.scene(variant, n=16)
+        uu = hr.make_uniforms(W, H, steps_count=27, step_size=1 / 16)
+        x, nx_, _ = ob.render(variant, uu, vols, tfs, W, H)
+        with ob.arithmetic(ob.FUSED):
+            y, ny_, _ = ob.render(variant, uu, vols, tfs, W, H)
+        assert float(np.max(np.abs(x - y))) <= 1e-4, variant
+        assert not np.array_equal(x.view(np.uint32), y.view(np.uint32)), variant
+    assert ob.load().vro_get_arithmetic() == 0

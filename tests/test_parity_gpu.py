@@ -637,3 +637,90 @@ def test_longest_first_launch_order_changes_nothing(ctx):
                     assert total == n_ref
     finally:
         ctx.set_kernel_flavour(0)
+
+
+# ---- fused arithmetic mode (vr_set_arithmetic): bit-exact against the oracle's fused mode --------------------------------
+@pytest.fixture
+def fused(ctx):
+    ctx.set_arithmetic(capi.ARITH_FUSED)
+    with ob.arithmetic(ob.FUSED):
+        yield ctx
+    ctx.set_arithmetic(capi.ARITH_SEPARATE)
+    ctx.set_kernel_flavour(0)
+    ctx.set_volume_layout(0)
+
+
+@pytest.mark.parametrize("variant", range(8))
+def test_fused_every_variant_every_loop_form(fused, variant):
+    """Every shader x every kernel form (one / two / four lanes per ray, pipelined, leaping, no skipping) x clips, variable
+    step, jitter, ragged viewport: the kernels compiled with fused multiply-adds against the oracle's fused mode."""
+    W, H = 70, 45
+    vols, tfs = vt.scene(variant, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    for fl in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11):
+        fused.set_kernel_flavour(fl)
+        for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
+                   dict(distance=0.7, yaw=1.0)):
+            args = dict(steps_count=count, step_size=step)
+            args.update(kw)
+            check(fused, variant, hr.make_uniforms(W, H, **args), vols, tfs, W, H)
+
+
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.VOLUME_MASK, capi.LIGHT_INSHADER])
+@pytest.mark.parametrize("zeros", [0, 1, 9, 40, 64])
+def test_fused_empty_space_skipping_is_exact(fused, variant, zeros):
+    """The brick coordinate follows the cell coordinate's rounding (one rounding when fused): skipping stays exact."""
+    W, H, n = 96, 64, 40
+    vols, tfs = vt.scene(variant, n=n)
+    tfs[0] = zero_prefix_tf(64, zeros)
+    step, count = hr.stepping_params(n, n, n)
+    for cam in (dict(yaw=0.9, pitch=-0.3), dict(yaw=-2.1, pitch=0.6, distance=0.85)):
+        u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam)
+        outs = []
+        for fl in (0, 1, 5, 11):
+            fused.set_kernel_flavour(fl)
+            frag, n_s = check(fused, variant, u, vols, tfs, W, H)
+            outs.append((vt.bits(frag), n_s))
+        assert all(np.array_equal(o[0], outs[0][0]) and o[1] == outs[0][1] for o in outs)
+
+
+def test_fused_layouts_hostile_values_and_mode_switching(fused):
+    W, H, n = 64, 48, 16
+    # density plane, vec4 only, gradients on the fly
+    vols, tfs = vt.scene(capi.LIGHT, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
+    for mode in (0, 1, 2):
+        fused.set_volume_layout(mode)
+        for fl in (6, 1):
+            fused.set_kernel_flavour(fl)
+            check(fused, capi.LIGHT, u, vols, tfs, W, H)
+    fused.set_volume_layout(0)
+    # NaN / inf / negative densities
+    rng = np.random.default_rng(3)
+    v = np.zeros((n, n, n, 4), dtype=f32)
+    v[4:12, 4:12, 4:12, 3] = rng.random((8, 8, 8), dtype=f32) * f32(0.5)
+    v[..., :3] = rng.standard_normal((n, n, n, 3)).astype(f32)
+    v[2, 2, 2, 3] = -0.25
+    v[13, 3, 3, 3] = np.inf
+    v[3, 13, 13, 3] = np.nan
+    s16, c16 = hr.stepping_params(n, n, n)
+    u = hr.make_uniforms(W, H, steps_count=c16, step_size=s16)
+    tf = zero_prefix_tf(32, 3)
+    for variant in (capi.BASIC, capi.LIGHT):
+        ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
+        for fl in (0, 1, 6, 11):
+            fused.set_kernel_flavour(fl)
+            frag, _, ns = vt.gpu_render(fused, variant, u, [v], [tf])
+            assert same(frag, ref) and ns == n_ref, (variant, fl)
+    # switching the mode back and forth on one context: each render follows the mode set at the time
+    fused.set_kernel_flavour(0)
+    vols, tfs = vt.scene(capi.LIGHT, n=16)
+    u = hr.make_uniforms(W, H, steps_count=27, step_size=1 / 16)
+    f_fused, _ = check(fused, capi.LIGHT, u, vols, tfs, W, H)
+    fused.set_arithmetic(capi.ARITH_SEPARATE)
+    with ob.arithmetic(ob.SEPARATE):
+        f_sep, _ = check(fused, capi.LIGHT, u, vols, tfs, W, H)
+    fused.set_arithmetic(capi.ARITH_FUSED)
+    assert not np.array_equal(vt.bits(f_fused), vt.bits(f_sep))
+    assert float(np.max(np.abs(f_fused - f_sep))) <= 1e-4

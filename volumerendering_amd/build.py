@@ -30,11 +30,23 @@ def _sources(d: str, exts: tuple[str, ...]) -> list[str]:
 
 
 def build_hip(force: bool = False) -> str:
+    """Two translation units, compiled side by side: vr_api.hip (C ABI + kernels with separately rounded multiply-adds)
+    and vr_fused.hip (the march kernels once more with fused multiply-adds), linked into one libvr_hip.so."""
     target = os.path.join(HERE, "libvr_hip.so")
-    deps = [os.path.join(CSRC, f) for f in ("vr_api.hip", "vr_kernels.h", "vr_wtb.h", "vr_dp.h", "vr_device.h")]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "vr.h"))
-    if force or _newer(target, deps):
-        subprocess.run([HIPCC, *HIP_FLAGS, "-o", target, os.path.join(CSRC, "vr_api.hip")], check=True)
+    hdrs = [os.path.join(CSRC, f) for f in ("vr_kernels.h", "vr_wtb.h", "vr_dp.h", "vr_device.h", "vr_launch.h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "vr.h"))
+    flags = [f for f in HIP_FLAGS if f != "-shared"]
+    objs, procs = [], []
+    for name in ("vr_api", "vr_fused"):
+        src, obj = os.path.join(CSRC, name + ".hip"), os.path.join(CSRC, name + ".o")
+        objs.append(obj)
+        if force or _newer(obj, hdrs + [src]):
+            procs.append((name, subprocess.Popen([HIPCC, *flags, "-c", "-o", obj, src])))
+    for name, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, f"hipcc {name}.hip")
+    if procs or force or _newer(target, objs):
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, *objs], check=True)
     return target
 
 

@@ -23,6 +23,7 @@ VR_ERR_OOM = -5
 BASIC, LIGHT, VOLUME_MASK, THREE_FILES, MULTI_CTRT, TF_CALIB, ILLUSTRATIVE, LIGHT_INSHADER = range(8)
 VARIANT_NAMES = ["BASIC", "LIGHT", "VOLUME_MASK", "THREE_FILES", "MULTI_CTRT", "TF_CALIB", "ILLUSTRATIVE", "LIGHT_INSHADER"]
 TILE = 64
+ARITH_SEPARATE, ARITH_FUSED = 0, 1
 
 # every symbol include/vr.h declares (tests check that the library exports each of them)
 ABI_SYMBOLS = [
@@ -31,7 +32,7 @@ ABI_SYMBOLS = [
     "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
-    "vr_set_volume_layout", "vr_volume_layout", "vr_viewport",
+    "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic",
 ]
 
 
@@ -106,6 +107,7 @@ def load() -> C.CDLL:
     lib.vr_set_kernel_flavour.argtypes = [vp, i32]
     lib.vr_last_kernel_flavour.argtypes = [vp]
     lib.vr_set_volume_layout.argtypes = [vp, i32]
+    lib.vr_set_arithmetic.argtypes = [vp, i32]
     lib.vr_volume_layout.argtypes = [vp, i32, C.POINTER(C.c_int)]
     _lib = lib
     return lib
@@ -273,6 +275,10 @@ class Context:
 
     def last_kernel_flavour(self) -> int:
         return self._chk(self.lib.vr_last_kernel_flavour(self.h))
+
+    def set_arithmetic(self, mode: int):
+        """ARITH_SEPARATE (0, default) or ARITH_FUSED (1): per-sample a * b + c with two roundings or one (include/vr.h)."""
+        self._chk(self.lib.vr_set_arithmetic(self.h, mode))
 
     def set_volume_layout(self, mode: int):
         """0 density plane for .a fetches (default), 1 the reference's vec4 voxels only, 2 = 0 + lit gradients on the fly."""

@@ -2,9 +2,12 @@
 // No CPU fallback exists behind this ABI (and nothing under oracle/ is referenced): without a usable HIP
 // device vr_create fails with VR_ERR_HIP.
 #include "../../include/vr.h"
-#include "vr_kernels.h"
-#include "vr_wtb.h"
-#include "vr_dp.h"
+#include "vr_launch.h"
+
+// the same dispatch over the kernels compiled with fused multiply-adds (vr_fused.hip)
+namespace vrf {
+void launch_march(const vr::LaunchDesc& L, hipStream_t s, const vr::MarchParams& P);
+}
 
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +47,7 @@ struct vr_ctx {
     float* vol_dens[VR_MAX_VOLUMES] = {};     // scalar density plane of each slot (DevVolume::dens)
     size_t vol_dens_cap[VR_MAX_VOLUMES] = {};  // in voxels
     bool vol_grad_derived[VR_MAX_VOLUMES] = {};  // .rgb verified to be PreComputeGradient(false) of .a, bit for bit
+    int arith = VR_ARITH_SEPARATE;             // vr_set_arithmetic
     int layout_mode = 0;                       // vr_set_volume_layout: 0 density plane for .a fetches, 1 vec4 voxels only,
                                                // 2 plane + lit gradients derived on the fly
     float2* merged_bricks = nullptr;           // VOLUME_MASK: (CT density max, mask rgb max), rebuilt when stale
@@ -85,6 +89,7 @@ struct vr_ctx {
         bool valid = false;
     } order_ring[kOrderRing];
     unsigned long long order_seq = 0;
+    hipStream_t order_stream = nullptr;  // the sorts run here, behind their launch's event: never on a frame's critical path
     int order_mode = 1;  // 0 = launch the blocks in index order (VR_EXP_ORDER=0)
     unsigned launch_seq = 0;
     int cnt_buf = 0;                           // the buffer the last launch wrote
@@ -171,32 +176,6 @@ int alloc_frame(vr_ctx* c)
     return VR_OK;
 }
 
-template <int V, bool OTF = false>
-void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchParams& P)
-{
-    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK || V == V_LIGHT_INSHADER);
-#define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF>), grid, block, 0, s, P)
-    if constexpr (kCanSkip) {
-        if (P.brick_dist) {
-            if (off32) {
-                if (leap == 2) VR_LAUNCH(true, true, 2);
-                else if (leap == 3) VR_LAUNCH(true, true, 3);
-                else if (leap == 1) VR_LAUNCH(true, true, 1);
-                else VR_LAUNCH(true, true, 0);
-            } else {
-                if (leap == 2) VR_LAUNCH(false, true, 2);
-                else if (leap == 3) VR_LAUNCH(false, true, 3);
-                else if (leap == 1) VR_LAUNCH(false, true, 1);
-                else VR_LAUNCH(false, true, 0);
-            }
-            return;
-        }
-    }
-    if (off32) VR_LAUNCH(true, false, 0);
-    else VR_LAUNCH(false, false, 0);
-#undef VR_LAUNCH
-}
-
 // Inverse of a column-major 4x4 in double precision (cofactors); false if singular / not finite.
 bool invert4(const float* m, double* o)
 {
@@ -258,23 +237,6 @@ void hit_rectangle(const vr_uniforms& u, int W, int H, int rect[4])
     rect[1] = (int)clampd(y0 - 3.0, 0.0, (double)H);
     rect[2] = (int)clampd(x1 + 3.0, -1.0, (double)(W - 1));
     rect[3] = (int)clampd(y1 + 3.0, -1.0, (double)(H - 1));
-}
-
-template <int V, int K, bool PIPE>
-void launch_dp(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
-{
-    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
-#define VR_LAUNCH_DP(O, S) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K, PIPE>), grid, dim3(256), 0, s, P)
-    if constexpr (kCanSkip) {
-        if (P.brick_dist) {
-            if (off32) VR_LAUNCH_DP(true, true);
-            else VR_LAUNCH_DP(false, true);
-            return;
-        }
-    }
-    if (off32) VR_LAUNCH_DP(true, false);
-    else VR_LAUNCH_DP(false, false);
-#undef VR_LAUNCH_DP
 }
 
 // finite and of moderate size: products of a colour, a light term and a shading factor stay finite, so "x * 0 == 0"
@@ -453,7 +415,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
     if (P.n_blocks > 0) {
         // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
-        const bool wtb = (fl == 2 || fl == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0;
+        const bool wtb = (fl == 2 || fl == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0 && c->arith == VR_ARITH_SEPARATE;
         const int leap_mode = fl == 4 ? 1 : (fl == 5 ? 0 : (fl == 9 ? 2 : 3));
         const int dp = (fl == 7 || fl == 10) ? 4 : ((fl == 8 || fl == 11) ? 2 : 0);
         // gradients on the fly (one-lane kernel, lit shader): the volume's .rgb is verified to be the central difference of
@@ -469,6 +431,10 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // the slot's previous launch (kInFlight launches ago, possibly on another stream) must have finished before its
         // record buffer is written again or re-allocated: this is what bounds the launches in flight to kInFlight
         if (c->slot_used[cb]) VR_HIP(c, hipEventSynchronize(c->slot_done[cb]));
+        if (c->order_seq >= (unsigned long long)kInFlight) {  // ... and the sort that read those records
+            const vr_ctx::OrderSlot& po = c->order_ring[(c->order_seq - kInFlight) % kOrderRing];
+            if (po.valid && po.seq + kInFlight == c->order_seq) VR_HIP(c, hipStreamWaitEvent(s, po.sorted, 0));
+        }
         if (grid.x > c->block_counts_cap[cb]) {
             if (c->d_block_counts[cb]) (void)hipFree(c->d_block_counts[cb]);
             c->d_block_counts[cb] = nullptr;
@@ -479,75 +445,44 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         P.block_counts = c->d_block_counts[cb];
         c->cnt_buf = cb;
-        // launch order: the most recent sort (at most three launches old, so its buffer cannot be recycled under this
-        // launch) of a launch of the same shape; same stream -> ordered by the stream, other stream -> by its event
+        // launch order: the most recent sort of a launch of the same shape that is two or three launches old -- not the
+        // launch just before this one, whose sort has not even started (it runs on a side stream behind that launch), and
+        // not an older one, whose buffer may be recycled under this launch; ordered behind it by its event
         const unsigned long long okey = ((unsigned long long)grid.x << 32) ^ ((unsigned long long)block.x << 20) ^
                                         ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
                                         ((unsigned long long)fl << 44) ^ (packed ? 1ull << 63 : 0ull);
         P.order = nullptr;
-        if (c->order_mode == 1 && !wtb) {
+        const bool ordered = c->order_mode == 1 && !wtb && grid.x <= (unsigned)kOrderMaxBlocks;
+        if (ordered) {
             const vr_ctx::OrderSlot* best = nullptr;
             for (const auto& o : c->order_ring)
-                if (o.valid && o.key == okey && o.seq + 3 >= c->order_seq && (!best || (o.stream == s) > (best->stream == s) ||
-                                                                               ((o.stream == s) == (best->stream == s) && o.seq > best->seq)))
+                if (o.valid && o.key == okey && o.seq + 3 >= c->order_seq && o.seq + 2 <= c->order_seq && (!best || o.seq > best->seq))
                     best = &o;
             if (best) {
-                if (best->stream != s) VR_HIP(c, hipStreamWaitEvent(s, best->sorted, 0));
+                VR_HIP(c, hipStreamWaitEvent(s, best->sorted, 0));
                 P.order = best->buf;
             }
         }
         const int slot = (int)(c->ring.head % kRing);
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
         VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
-        if (wtb) {
-            if (P.brick_dist) {
-                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, P);
-                else hipLaunchKernelGGL((march_wtb_light_kernel<false, true>), grid, dim3(256), 0, s, P);
-            } else {
-                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, false>), grid, dim3(256), 0, s, P);
-                else hipLaunchKernelGGL((march_wtb_light_kernel<false, false>), grid, dim3(256), 0, s, P);
-            }
-        } else if (dp == 4) {
-            switch (variant) {
-            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4, false>(off32, grid, s, P); break;
-            case VR_VARIANT_LIGHT:
-                if (dp_pipe) launch_dp<V_LIGHT, 4, true>(off32, grid, s, P);
-                else launch_dp<V_LIGHT, 4, false>(off32, grid, s, P);
-                break;
-            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4, false>(off32, grid, s, P); break;
-            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4, false>(off32, grid, s, P); break;
-            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4, false>(off32, grid, s, P); break;
-            default: launch_dp<V_TF_CALIB, 4, false>(off32, grid, s, P); break;
-            }
-        } else if (dp == 2) {
-            switch (variant) {
-            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2, false>(off32, grid, s, P); break;
-            case VR_VARIANT_LIGHT:
-                if (dp_pipe) launch_dp<V_LIGHT, 2, true>(off32, grid, s, P);
-                else launch_dp<V_LIGHT, 2, false>(off32, grid, s, P);
-                break;
-            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2, false>(off32, grid, s, P); break;
-            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2, false>(off32, grid, s, P); break;
-            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2, false>(off32, grid, s, P); break;
-            default: launch_dp<V_TF_CALIB, 2, false>(off32, grid, s, P); break;
-            }
-        } else
-        switch (variant) {
-        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_LIGHT:
-            if (otf) launch_variant<V_LIGHT, true>(off32, leap_mode, grid, block, s, P);
-            else launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, P);
-            break;
-        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_ILLUSTRATIVE: launch_variant<V_ILLUSTRATIVE>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_LIGHT_INSHADER: launch_variant<V_LIGHT_INSHADER>(off32, leap_mode, grid, block, s, P); break;
-        default: launch_variant<V_TF_CALIB>(off32, leap_mode, grid, block, s, P); break;
+        {
+            LaunchDesc L;
+            L.variant = variant;
+            L.off32 = off32;
+            L.leap_mode = leap_mode;
+            L.dp = dp;
+            L.dp_pipe = dp_pipe;
+            L.wtb = wtb;
+            L.otf = otf;
+            L.grid = grid;
+            L.block = block;
+            if (c->arith == VR_ARITH_FUSED) vrf::launch_march(L, s, P);
+            else vr::launch_march(L, s, P);
         }
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
-        if (c->order_mode == 1 && !wtb) {
+        if (ordered) {
             vr_ctx::OrderSlot& o = c->order_ring[c->order_seq % kOrderRing];
             o.valid = false;
             if (grid.x > o.cap) {
@@ -557,17 +492,21 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 VR_HIP(c, hipMalloc(&o.buf, (size_t)grid.x * sizeof(unsigned)));
                 o.cap = grid.x;
             }
-            hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, s, c->d_block_counts[cb], (int)grid.x, o.buf);
-            VR_HIP(c, hipGetLastError());
-            VR_HIP(c, hipEventRecord(o.sorted, s));
             o.stream = s;
             o.key = okey;
             o.seq = c->order_seq;
+        }
+        VR_HIP(c, hipEventRecord(c->slot_done[cb], s));
+        c->slot_used[cb] = true;
+        if (ordered) {
+            vr_ctx::OrderSlot& o = c->order_ring[c->order_seq % kOrderRing];
+            VR_HIP(c, hipStreamWaitEvent(c->order_stream, c->slot_done[cb], 0));
+            hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, c->order_stream, c->d_block_counts[cb], (int)grid.x, o.buf);
+            VR_HIP(c, hipGetLastError());
+            VR_HIP(c, hipEventRecord(o.sorted, c->order_stream));
             o.valid = true;
         }
         ++c->order_seq;
-        VR_HIP(c, hipEventRecord(c->slot_done[cb], s));
-        c->slot_used[cb] = true;
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
         ++c->ring.head;
         c->cnt_blocks = (int)grid.x;
@@ -824,6 +763,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
         if (!hip_ok(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming), "hipEventCreate")) return bail(VR_ERR_HIP);
     for (auto& o : c->order_ring)
         if (!hip_ok(hipEventCreateWithFlags(&o.sorted, hipEventDisableTiming), "hipEventCreate")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipStreamCreateWithFlags(&c->order_stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(VR_ERR_HIP);
     if (const char* e = getenv("VR_EXP_ORDER")) c->order_mode = atoi(e);
     if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 3 * sizeof(unsigned long long), hipHostMallocDefault),
@@ -882,6 +822,7 @@ void vr_destroy(vr_ctx* c)
         if (o.sorted) (void)hipEventDestroy(o.sorted);
         if (o.buf) (void)hipFree(o.buf);
     }
+    if (c->order_stream) (void)hipStreamDestroy(c->order_stream);
     if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
     if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);
     if (c->tm.ev_k1) (void)hipEventDestroy(c->tm.ev_k1);
@@ -1186,6 +1127,14 @@ int vr_last_kernel_flavour(vr_ctx* c)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     return c->last_flavour;
+}
+
+int vr_set_arithmetic(vr_ctx* c, int mode)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (mode != VR_ARITH_SEPARATE && mode != VR_ARITH_FUSED) return fail(c, VR_ERR_INVALID_ARG, "vr_set_arithmetic: unknown mode");
+    c->arith = mode;
+    return VR_OK;
 }
 
 int vr_set_volume_layout(vr_ctx* c, int mode)

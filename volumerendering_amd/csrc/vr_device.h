@@ -76,4 +76,17 @@ struct MarchParams {
     unsigned long long* block_counts;  // [gridDim.x][kBlockRecord]: composited, covered, fetched, t0, t1, hw id
 };
 
+// What enqueue_render decided about one march launch; handed to launch_march of the arithmetic mode's translation unit
+// (vr_launch.h: namespace vr = separately rounded multiply-adds, namespace vrf = fused).
+struct LaunchDesc {
+    int variant;      // vr_variant
+    bool off32;       // every bound volume < 4 GiB: 32-bit byte offsets
+    int leap_mode;    // LEAP template argument of march_kernel
+    int dp;           // lanes per ray of march_dp_kernel (2 / 4), 0 = march_kernel
+    bool dp_pipe;     // ... with the next round's corner loads software-pipelined
+    bool wtb;         // LDS wave-tile kernel (lit shader, separate arithmetic only)
+    bool otf;         // lit shader: corner gradients derived from the density plane
+    dim3 grid, block;
+};
+
 }  // namespace vr

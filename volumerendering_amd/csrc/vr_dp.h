@@ -16,7 +16,8 @@
 #pragma once
 #include "vr_kernels.h"
 
-namespace vr {
+namespace VR_KNS {
+using namespace vr;
 
 // The value depth slot J of the lane's own ray holds (K lanes per ray, K = 2 or 4, rays aligned to quads).
 template <int K, int J>
@@ -77,7 +78,7 @@ __device__ __forceinline__ void dp_blend_slot(int flags, v2f s_rg, v2f s_ba, v2f
     blends += counted ? 1u : 0u;
     fetched += real ? 1u : 0u;
     const float om = 1.0f - dzw.y;           // FrontToBackBlend, src already (rgb * a, a)
-    const v2f nxy = rg * om + dxy, nzw = ba * om + dzw;
+    const v2f nxy = mad2(rg, v2f{om, om}, dxy), nzw = mad2(ba, v2f{om, om}, dzw);
     dxy = real ? nxy : dxy;
     dzw = real ? nzw : dzw;
     const bool cut = real && !can_blend<V>(dzw.y);        // cut-off reached: no later step can blend
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
         if (ray.hit) {
             covered = 1;
             f3 diff = mk3(ray.end.x - ray.start.x, ray.end.y - ray.start.y, ray.end.z - ray.start.z);
-            f3 dir = normalize3(diff);
-            float ray_len = length3(diff);
+            f3 dir = normalize3s(diff);
+            float ray_len = length3s(diff);
             if (P.fragment_mode == 1) {
                 dst = make_float4(fabsf(dir.x), fabsf(dir.y), fabsf(dir.z), 1.0f);
             } else if (P.fragment_mode == 2) {
@@ -281,4 +282,4 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
     store_block_counts(P, j == 0 ? blends : 0u, j == 0 ? covered : 0u, j == 0 ? fetched : 0u, t_start);
 }
 
-}  // namespace vr
+}  // namespace VR_KNS

@@ -22,7 +22,18 @@
 #pragma once
 #include "vr_device.h"
 
-namespace vr {
+// The kernels are compiled once per arithmetic mode, each in a translation unit and a namespace of its own:
+//   VR_KNS = vr,  VR_FUSED = 0   a * b + c rounds the product and the sum separately (the default normative arithmetic)
+//   VR_KNS = vrf, VR_FUSED = 1   the per-sample expressions of that shape are single fused multiply-adds (vr_fused.hip)
+#ifndef VR_KNS
+#define VR_KNS vr
+#endif
+#ifndef VR_FUSED
+#define VR_FUSED 0
+#endif
+
+namespace VR_KNS {
+using namespace vr;
 
 enum Variant : int { V_BASIC = 0, V_LIGHT = 1, V_VOLUME_MASK = 2, V_THREE_FILES = 3, V_MULTI_CTRT = 4, V_TF_CALIB = 5,
                      V_ILLUSTRATIVE = 6, V_LIGHT_INSHADER = 7 };
@@ -32,7 +43,23 @@ struct f3 {
 };
 
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+// a * b + c of the PER-SAMPLE expressions: two roundings (VR_FUSED 0, the default normative arithmetic) or one
+// (VR_FUSED 1).  Ray placement never goes through this: it is separately rounded in both modes (dot3s / normalize3s).
+__device__ __forceinline__ float mad(float a, float b, float c)
+{
+#if VR_FUSED
+    return __builtin_fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+__device__ __forceinline__ float dot3s(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length3s(f3 a) { return sqrtf(dot3s(a, a)); }
+#if VR_FUSED
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return mad(a.z, b.z, mad(a.y, b.y, a.x * b.x)); }
+#else
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+#endif
 __device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
 // 1.0f / sqrtf(x), both operations correctly rounded (the normative normalize = v * (1 / sqrt(dot))).  For x in
 // [2^-60, 2^60) the compiler's IEEE expansions need none of their scaling and special-case steps; what is left is
@@ -61,8 +88,13 @@ __device__ __forceinline__ f3 normalize3(f3 a)
     float inv = inv_sqrt_exact(dot3(a, a));
     return mk3(a.x * inv, a.y * inv, a.z * inv);
 }
+__device__ __forceinline__ f3 normalize3s(f3 a)
+{
+    float inv = inv_sqrt_exact(dot3s(a, a));
+    return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
 __device__ __forceinline__ float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
-__device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return mad(b - a, t, a); }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 // Texel pair of a clamp-to-edge linear fetch from the floored coordinate x0 (any float, incl. +-inf / NaN):
 // the f32 -> i32 conversion saturates (NaN -> 0, v_cvt_i32_f32), and the "+1" is applied after limiting the
@@ -198,9 +230,9 @@ __device__ __forceinline__ void texel_step(float x0, int n, int& i0, bool& next)
 }
 __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
 {
-    float x = p.x * (float)v.nx - 0.5f;
-    float y = p.y * (float)v.ny - 0.5f;
-    float z = p.z * (float)v.nz - 0.5f;
+    float x = mad(p.x, (float)v.nx, -0.5f);
+    float y = mad(p.y, (float)v.ny, -0.5f);
+    float z = mad(p.z, (float)v.nz, -0.5f);
     float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
     Cell c;
     c.fx = x - x0;
@@ -354,7 +386,7 @@ __device__ __forceinline__ float4 corner_otf(const DevVolume& v, int i, int j, i
 template <bool OFF32>
 __device__ __forceinline__ void fetch_rgba_otf(const DevVolume& v, f3 p, Fetch4& q, float& fx, float& fy, float& fz)
 {
-    const float x = p.x * (float)v.nx - 0.5f, y = p.y * (float)v.ny - 0.5f, z = p.z * (float)v.nz - 0.5f;
+    const float x = mad(p.x, (float)v.nx, -0.5f), y = mad(p.y, (float)v.ny, -0.5f), z = mad(p.z, (float)v.nz, -0.5f);
     const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
     fx = x - x0;
     fy = y - y0;
@@ -395,7 +427,16 @@ __device__ __forceinline__ void fetch_rgba_otf(const DevVolume& v, f3 p, Fetch4&
 // Two channels at a time (packed f32 on the register halves the 16-byte loads deliver: no shuffling).  Per lane
 // and per channel the operations and their order are those of tri(): a + (b - a) * t, separately rounded.
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f lerp2(v2f a, v2f b, float t) { return a + (b - a) * t; }
+// a * b + c on a register pair (v_pk_fma_f32 when fused)
+__device__ __forceinline__ v2f mad2(v2f a, v2f b, v2f c)
+{
+#if VR_FUSED
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+__device__ __forceinline__ v2f lerp2(v2f a, v2f b, float t) { return mad2(b - a, v2f{t, t}, a); }
 __device__ __forceinline__ v2f tri2(v2f v000, v2f v100, v2f v010, v2f v110, v2f v001, v2f v101, v2f v011, v2f v111,
                                     float fx, float fy, float fz)
 {
@@ -473,7 +514,7 @@ __device__ __forceinline__ TfFetch tf_fetch(const DevTF& tf, float d)
 {
     // the opacity and the colour texture are separate 1-D textures, each with its own resolution; when the two are
     // equal (every scene of the reference, until a preset of another size is loaded) index and weight are shared
-    float xo = d * (float)tf.res_o - 0.5f;
+    float xo = mad(d, (float)tf.res_o, -0.5f);
     float xo0 = floorf(xo);
     TfFetch q;
     q.fo = xo - xo0;
@@ -481,7 +522,7 @@ __device__ __forceinline__ TfFetch tf_fetch(const DevTF& tf, float d)
     int jc = jo;
     q.fc = q.fo;
     if (tf.res_c != tf.res_o) {  // wave-uniform
-        float xc = d * (float)tf.res_c - 0.5f;
+        float xc = mad(d, (float)tf.res_c, -0.5f);
         float xc0 = floorf(xc);
         q.fc = xc - xc0;
         jc = padded_texel(xc0, tf.res_c);
@@ -537,8 +578,8 @@ __device__ inline Ray setup_ray(const MarchParams& P, int px, int py)
     f3 O = unproject(P, ndcx, ndcy, 0.0f);
     f3 F = unproject(P, ndcx, ndcy, 1.0f);
     f3 D = mk3(F.x - O.x, F.y - O.y, F.z - O.z);
-    float seg = length3(D);
-    f3 dn = normalize3(D);
+    float seg = length3s(D);
+    f3 dn = normalize3s(D);
     float o[3] = {O.x, O.y, O.z}, d[3] = {dn.x, dn.y, dn.z};
     float t0 = -INFINITY, t1 = INFINITY;
     int a0 = -1, a1 = -1;
@@ -584,17 +625,17 @@ __device__ __forceinline__ f3 shade(f3 N, f3 w, f3 lpos, f3 dif, f3 amb, float k
 {
     f3 L = normalize3(mk3(lpos.x - w.x, lpos.y - w.y, lpos.z - w.z));
     float m = max0(dot3(N, L));
-    return mk3((dif.x * m) * kD + amb.x * kA, (dif.y * m) * kD + amb.y * kA, (dif.z * m) * kD + amb.z * kA);
+    return mk3(mad(dif.x * m, kD, amb.x * kA), mad(dif.y * m, kD, amb.y * kA), mad(dif.z * m, kD, amb.z * kA));
 }
 
 __device__ __forceinline__ void blend(f3 rgb, float a, float4& dst)  // FrontToBackBlend
 {
     float sr = rgb.x * a, sg = rgb.y * a, sb = rgb.z * a;
     float om = 1.0f - dst.w;
-    dst.x = om * sr + dst.x;
-    dst.y = om * sg + dst.y;
-    dst.z = om * sb + dst.z;
-    dst.w = om * a + dst.w;
+    dst.x = mad(om, sr, dst.x);
+    dst.y = mad(om, sg, dst.y);
+    dst.z = mad(om, sb, dst.z);
+    dst.w = mad(om, a, dst.w);
 }
 
 template <int V>
@@ -671,8 +712,8 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
         TfSample tct = tf_lookup(P.tf[0], ct);
         TfSample trt = tf_lookup(P.tf[1], rt);
         float om = 1.0f - trt.opacity;
-        o.rgb = mk3(tct.rgb.x * om + trt.rgb.x * trt.opacity, tct.rgb.y * om + trt.rgb.y * trt.opacity,
-                    tct.rgb.z * om + trt.rgb.z * trt.opacity);
+        o.rgb = mk3(mad(trt.rgb.x, trt.opacity, tct.rgb.x * om), mad(trt.rgb.y, trt.opacity, tct.rgb.y * om),
+                    mad(trt.rgb.z, trt.opacity, tct.rgb.z * om));
         o.a = tct.opacity;
     } else if constexpr (V == V_MULTI_CTRT) {
         float4 ct = tex3_rgba<OFF32>(P.vol[0], p);
@@ -680,8 +721,8 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
         TfSample tct = tf_lookup(P.tf[0], ct.w);
         TfSample trt = tf_lookup(P.tf[1], rt);
         float om = 1.0f - trt.opacity;
-        f3 col = mk3(tct.rgb.x * om + trt.rgb.x * trt.opacity, tct.rgb.y * om + trt.rgb.y * trt.opacity,
-                     tct.rgb.z * om + trt.rgb.z * trt.opacity);
+        f3 col = mk3(mad(trt.rgb.x, trt.opacity, tct.rgb.x * om), mad(trt.rgb.y, trt.opacity, tct.rgb.y * om),
+                     mad(trt.rgb.z, trt.opacity, tct.rgb.z * om));
         f3 g = mk3(ct.x, ct.y, ct.z);
         f3 N = normalize3(g);
         f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
@@ -694,8 +735,8 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
         TfSample tct = tf_lookup(P.tf[0], ct.w);
         TfSample trt = tf_lookup(P.tf[1], rt);
         float om = 1.0f - trt.opacity;
-        f3 col = mk3(tct.rgb.x * om + trt.rgb.x * trt.opacity, tct.rgb.y * om + trt.rgb.y * trt.opacity,
-                     tct.rgb.z * om + trt.rgb.z * trt.opacity);
+        f3 col = mk3(mad(trt.rgb.x, trt.opacity, tct.rgb.x * om), mad(trt.rgb.y, trt.opacity, tct.rgb.y * om),
+                     mad(trt.rgb.z, trt.opacity, tct.rgb.z * om));
         f3 g = mk3(ct.x, ct.y, ct.z);
         f3 N = normalize3(g);
         f3 s3 = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
@@ -738,31 +779,43 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         const v2f zw = interp_zw(q, fx, fy, fz);  // (gradient z, density)
         const TfFetch tq = tf_fetch(P.tf[0], zw.y);
         const v2f gxy = interp_xy(q, fx, fy, fz);
+#if VR_FUSED
+        const float inv_g = inv_sqrt_exact(mad(zw.x, zw.x, mad(gxy.y, gxy.y, gxy.x * gxy.x)));
+#else
         const v2f g2 = gxy * gxy;
         const float inv_g = inv_sqrt_exact((g2.x + g2.y) + zw.x * zw.x);
+#endif
         const v2f Nxy = gxy * inv_g;
         const float Nz = zw.x * inv_g;
         v2f Lxy = v2f{P.light_pos[0] - w.x, P.light_pos[1] - w.y};
         float Lz = P.light_pos[2] - w.z;
+#if VR_FUSED
+        const float inv_l = inv_sqrt_exact(mad(Lz, Lz, mad(Lxy.y, Lxy.y, Lxy.x * Lxy.x)));
+#else
         const v2f l2 = Lxy * Lxy;
         const float inv_l = inv_sqrt_exact((l2.x + l2.y) + Lz * Lz);
+#endif
         Lxy = Lxy * inv_l;
         Lz = Lz * inv_l;
+#if VR_FUSED
+        const float m = max0(mad(Nz, Lz, mad(Nxy.y, Lxy.y, Nxy.x * Lxy.x)));
+#else
         const v2f nl = Nxy * Lxy;
         const float m = max0((nl.x + nl.y) + Nz * Lz);
-        const v2f sh_rg = (v2f{P.light_dif[0], P.light_dif[1]} * m) * 2.5f + v2f{P.light_amb[0], P.light_amb[1]} * 0.5f;
-        const float sh_b = (P.light_dif[2] * m) * 2.5f + P.light_amb[2] * 0.5f;
+#endif
+        const v2f sh_rg = mad2(v2f{P.light_dif[0], P.light_dif[1]} * m, v2f{2.5f, 2.5f}, v2f{P.light_amb[0], P.light_amb[1]} * 0.5f);
+        const float sh_b = mad(P.light_dif[2] * m, 2.5f, P.light_amb[2] * 0.5f);
         const float opacity = lerpf(tq.o0, tq.o1, tq.fo);
         const v2f c_rg = lerp2(v2f{tq.c0.x, tq.c0.y}, v2f{tq.c1.x, tq.c1.y}, tq.fc);
         const float c_b = lerpf(tq.c0.z, tq.c1.z, tq.fc);
         const v2f src_rg = (c_rg * sh_rg) * opacity;  // FrontToBackBlend: (rgb * a, a)
         const float src_b = (c_b * sh_b) * opacity;
         const float om = 1.0f - dst.w;
-        const v2f d_rg = src_rg * om + v2f{dst.x, dst.y};
+        const v2f d_rg = mad2(src_rg, v2f{om, om}, v2f{dst.x, dst.y});
         dst.x = d_rg.x;
         dst.y = d_rg.y;
-        dst.z = om * src_b + dst.z;
-        dst.w = om * opacity + dst.w;
+        dst.z = mad(om, src_b, dst.z);
+        dst.w = mad(om, opacity, dst.w);
     } else {
         const Src s = sample_src<V, OFF32, OTF>(P, p, w, start, dst.w, ss);
         blend(s.rgb, s.a, dst);
@@ -837,15 +890,16 @@ __device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
     if constexpr (FMED) {
         // The clamp is taken in float (one v_med3_f32; a NaN comes out as 0 either way) and truncation of the clamped,
         // non-negative value is its floor: four instructions per axis.
-        bx = (int)__builtin_amdgcn_fmed3f(p.x * P.bsx - 0.0625f, 0.0f, (float)(P.bnx - 1));
-        by = (int)__builtin_amdgcn_fmed3f(p.y * P.bsy - 0.0625f, 0.0f, (float)(P.bny - 1));
-        bz = (int)__builtin_amdgcn_fmed3f(p.z * P.bsz - 0.0625f, 0.0f, (float)(P.bnz - 1));
+        // (mad: the same rounding(s) as the cell's own coordinate p * n - 0.5 -- scaling by 1/8 commutes with either)
+        bx = (int)__builtin_amdgcn_fmed3f(mad(p.x, P.bsx, -0.0625f), 0.0f, (float)(P.bnx - 1));
+        by = (int)__builtin_amdgcn_fmed3f(mad(p.y, P.bsy, -0.0625f), 0.0f, (float)(P.bny - 1));
+        bz = (int)__builtin_amdgcn_fmed3f(mad(p.z, P.bsz, -0.0625f), 0.0f, (float)(P.bnz - 1));
     } else {
         // (integer clamps: the 64-bit-address kernels sit at the register limit of five waves per SIMD and the float
         // form costs them four more)
-        bx = clampi((int)floorf(p.x * P.bsx - 0.0625f), 0, P.bnx - 1);
-        by = clampi((int)floorf(p.y * P.bsy - 0.0625f), 0, P.bny - 1);
-        bz = clampi((int)floorf(p.z * P.bsz - 0.0625f), 0, P.bnz - 1);
+        bx = clampi((int)floorf(mad(p.x, P.bsx, -0.0625f)), 0, P.bnx - 1);
+        by = clampi((int)floorf(mad(p.y, P.bsy, -0.0625f)), 0, P.bny - 1);
+        bz = clampi((int)floorf(mad(p.z, P.bsz, -0.0625f)), 0, P.bnz - 1);
     }
     return __mul24(__mul24(bz, P.bny) + by, P.bnx) + bx;  // < 2^24 bricks per axis pair: 24-bit multiplies are exact
 }
@@ -955,7 +1009,7 @@ __device__ __forceinline__ int leap_apply(const LeapCoord& c, int m, float& out)
 __device__ __forceinline__ float leap_axis(float p, float s, float bs, int nb, int k, float inv_n)
 {
     if (s == 0.0f) return 1.0e9f;
-    const int b = clampi((int)floorf(p * bs - 0.0625f), 0, nb - 1);
+    const int b = clampi((int)floorf(mad(p, bs, -0.0625f)), 0, nb - 1);
     float room;
     if (s > 0.0f) {
         const int hi = b + k;  // last inert brick index in the direction of travel
@@ -984,8 +1038,8 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
         if (ray.hit) {
             covered = 1;
             f3 diff = mk3(ray.end.x - ray.start.x, ray.end.y - ray.start.y, ray.end.z - ray.start.z);
-            f3 dir = normalize3(diff);
-            float ray_len = length3(diff);
+            f3 dir = normalize3s(diff);
+            float ray_len = length3s(diff);
             if (P.fragment_mode == 1) {
                 dst = make_float4(fabsf(dir.x), fabsf(dir.y), fabsf(dir.z), 1.0f);
             } else if (P.fragment_mode == 2) {
@@ -1247,6 +1301,7 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
     store_block_counts(P, blends, covered, fetched, t_start);
 }
 
+#if !VR_FUSED  // auxiliary kernels (no multiply-adds of the per-sample kind): compiled once, in namespace vr
 // One wavefront per brick: maximum of .a over the voxels [8b, min(8b+8, n-1)]^3 (NaN if any voxel is NaN).
 __global__ __launch_bounds__(64) void brick_max_kernel(const float4* __restrict__ vol, int nx, int ny, int nz, int bnx,
                                                        int bny, float2* __restrict__ out)
@@ -1339,32 +1394,51 @@ __global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned lo
 // One workgroup: order[] = the logical blocks of the launch whose records are `in`, sorted by the longest per-ray sample
 // chain of the block (record word 5, bits 40..), longest first -- a counting sort over 1024 key buckets.  The next
 // frame's workgroups take their blocks in this order (MarchParams::order): longest-processing-time-first scheduling.
+constexpr int kOrderMaxBlocks = 32 * 1024;  // launches with more blocks keep the index order
 __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long long* __restrict__ in, int n_blocks,
                                                             unsigned* __restrict__ order)
 {
     __shared__ unsigned hist[1024];
     __shared__ unsigned base[1024];
+    __shared__ unsigned wave_total[16];
     const int t = threadIdx.x;
     hist[t] = 0;
     __syncthreads();
-    // bucket 0 = the longest chains; chains beyond 1023 * 4 share bucket 0
-    auto bucket = [&](int b) {
-        const unsigned long long crit = in[(size_t)b * kBlockRecord + 5] >> 40;
-        const unsigned k = (unsigned)(crit >> 2);
-        return 1023u - (k > 1023u ? 1023u : k);
-    };
-    for (int b = t; b < n_blocks; b += 1024) atomicAdd(&hist[bucket(b)], 1u);
-    __syncthreads();
-    if (t == 0) {
-        unsigned acc = 0;
-        for (int k = 0; k < 1024; ++k) {
-            base[k] = acc;
-            acc += hist[k];
+    // every record is read ONCE (a launch that recycles the record buffer under this kernel can then only change the
+    // order, never make it something other than a permutation); bucket 0 = the longest chains
+    unsigned short bk[kOrderMaxBlocks / 1024];
+#pragma unroll
+    for (int k = 0; k < kOrderMaxBlocks / 1024; ++k) {
+        const int b = t + k * 1024;
+        if (b < n_blocks) {
+            const unsigned long long crit = in[(size_t)b * kBlockRecord + 5] >> 40;
+            const unsigned q = (unsigned)(crit >> 2);
+            bk[k] = (unsigned short)(1023u - (q > 1023u ? 1023u : q));
+            atomicAdd(&hist[bk[k]], 1u);
         }
     }
     __syncthreads();
+    {   // exclusive prefix sum of the 1024 bucket counts: wave scan, then the 16 wave totals
+        const unsigned mine = hist[t];
+        unsigned incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, off, 64);
+            if ((t & 63) >= off) incl += up;
+        }
+        if ((t & 63) == 63) wave_total[t >> 6] = incl;
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < (t >> 6); ++w) before += wave_total[w];
+        base[t] = before + incl - mine;
+    }
+    __syncthreads();
     // scatter with one cursor per bucket (the order inside a bucket does not matter)
-    for (int b = t; b < n_blocks; b += 1024) order[atomicAdd(&base[bucket(b)], 1u)] = (unsigned)b;
+#pragma unroll
+    for (int k = 0; k < kOrderMaxBlocks / 1024; ++k) {
+        const int b = t + k * 1024;
+        if (b < n_blocks) order[atomicAdd(&base[bk[k]], 1u)] = (unsigned)b;
+    }
 }
 
 // ---- brick distance field (rebuilt when the volume or the opacity table changes) --------------------------------
@@ -1527,4 +1601,6 @@ __global__ void scale_gradient_kernel(float4* __restrict__ vol, size_t n, const 
     }
 }
 
-}  // namespace vr
+#endif  // !VR_FUSED
+
+}  // namespace VR_KNS

@@ -1,0 +1,115 @@
+// vr_launch.h -- picks the instantiation of the march kernels for one launch (variant x addressing x skipping x loop
+// form x lanes per ray).  Included once per arithmetic mode: by vr_api.hip (namespace vr, separately rounded
+// multiply-adds) and by vr_fused.hip (namespace vrf, fused multiply-adds); enqueue_render calls the one the context's
+// arithmetic mode selects (vr_set_arithmetic).
+#pragma once
+#include "../../include/vr.h"
+#include "vr_kernels.h"
+#include "vr_dp.h"
+#if !VR_FUSED
+#include "vr_wtb.h"
+#endif
+
+namespace VR_KNS {
+
+template <int V, bool OTF = false>
+void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchParams& P)
+{
+    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK || V == V_LIGHT_INSHADER);
+#define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF>), grid, block, 0, s, P)
+    if constexpr (kCanSkip) {
+        if (P.brick_dist) {
+            if (off32) {
+                if (leap == 2) VR_LAUNCH(true, true, 2);
+                else if (leap == 3) VR_LAUNCH(true, true, 3);
+                else if (leap == 1) VR_LAUNCH(true, true, 1);
+                else VR_LAUNCH(true, true, 0);
+            } else {
+                if (leap == 2) VR_LAUNCH(false, true, 2);
+                else if (leap == 3) VR_LAUNCH(false, true, 3);
+                else if (leap == 1) VR_LAUNCH(false, true, 1);
+                else VR_LAUNCH(false, true, 0);
+            }
+            return;
+        }
+    }
+    if (off32) VR_LAUNCH(true, false, 0);
+    else VR_LAUNCH(false, false, 0);
+#undef VR_LAUNCH
+}
+
+template <int V, int K, bool PIPE>
+void launch_dp(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
+{
+    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
+#define VR_LAUNCH_DP(O, S) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K, PIPE>), grid, dim3(256), 0, s, P)
+    if constexpr (kCanSkip) {
+        if (P.brick_dist) {
+            if (off32) VR_LAUNCH_DP(true, true);
+            else VR_LAUNCH_DP(false, true);
+            return;
+        }
+    }
+    if (off32) VR_LAUNCH_DP(true, false);
+    else VR_LAUNCH_DP(false, false);
+#undef VR_LAUNCH_DP
+}
+
+void launch_march(const LaunchDesc& L, hipStream_t s, const MarchParams& P)
+{
+    const int variant = L.variant;
+    const bool off32 = L.off32, dp_pipe = L.dp_pipe, otf = L.otf;
+    const int leap_mode = L.leap_mode, dp = L.dp;
+    const dim3 grid = L.grid, block = L.block;
+#if !VR_FUSED
+        if (L.wtb) {
+            if (P.brick_dist) {
+                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, P);
+                else hipLaunchKernelGGL((march_wtb_light_kernel<false, true>), grid, dim3(256), 0, s, P);
+            } else {
+                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, false>), grid, dim3(256), 0, s, P);
+                else hipLaunchKernelGGL((march_wtb_light_kernel<false, false>), grid, dim3(256), 0, s, P);
+            }
+        } else
+#endif
+        if (dp == 4) {
+            switch (variant) {
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4, false>(off32, grid, s, P); break;
+            case VR_VARIANT_LIGHT:
+                if (dp_pipe) launch_dp<V_LIGHT, 4, true>(off32, grid, s, P);
+                else launch_dp<V_LIGHT, 4, false>(off32, grid, s, P);
+                break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4, false>(off32, grid, s, P); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4, false>(off32, grid, s, P); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4, false>(off32, grid, s, P); break;
+            default: launch_dp<V_TF_CALIB, 4, false>(off32, grid, s, P); break;
+            }
+        } else if (dp == 2) {
+            switch (variant) {
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2, false>(off32, grid, s, P); break;
+            case VR_VARIANT_LIGHT:
+                if (dp_pipe) launch_dp<V_LIGHT, 2, true>(off32, grid, s, P);
+                else launch_dp<V_LIGHT, 2, false>(off32, grid, s, P);
+                break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2, false>(off32, grid, s, P); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2, false>(off32, grid, s, P); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2, false>(off32, grid, s, P); break;
+            default: launch_dp<V_TF_CALIB, 2, false>(off32, grid, s, P); break;
+            }
+        } else
+        switch (variant) {
+        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_LIGHT:
+            if (otf) launch_variant<V_LIGHT, true>(off32, leap_mode, grid, block, s, P);
+            else launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, P);
+            break;
+        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_ILLUSTRATIVE: launch_variant<V_ILLUSTRATIVE>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_LIGHT_INSHADER: launch_variant<V_LIGHT_INSHADER>(off32, leap_mode, grid, block, s, P); break;
+        default: launch_variant<V_TF_CALIB>(off32, leap_mode, grid, block, s, P); break;
+        }
+}
+
+}  // namespace VR_KNS

@@ -9,7 +9,8 @@
 #pragma once
 #include "vr_kernels.h"
 
-namespace vr {
+namespace VR_KNS {
+using namespace vr;
 
 constexpr int kWtbCap = 448;  // float4 voxels per tile: 7 KiB of LDS per wavefront (22 wavefronts per CU by LDS)
 
@@ -263,4 +264,4 @@ __global__ __launch_bounds__(256) void march_wtb_light_kernel(const MarchParams 
     store_block_counts(P, blends, covered, fetched, t_start);
 }
 
-}  // namespace vr
+}  // namespace VR_KNS
