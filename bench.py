@@ -109,6 +109,7 @@ def pmc_child(args):
         if args.flavour:
             app.context().set_kernel_flavour(args.flavour)
         app.context().set_volume_layout(args.layout)
+        app.context().set_arithmetic(1 if args.arith == "fused" else 0)
         for _ in range(4):
             app.OnRender()
 
@@ -128,7 +129,7 @@ def live_pmc(args, passes=PMC_PASSES, timeout_s=150):
         d = os.path.join(tmp, f"pass{i}")
         cmd = [prof, "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload, "--tf", args.tf, "--air", args.air,
-               "--flavour", str(args.flavour), "--vol-n", str(args.vol_n), "--layout", str(args.layout)]
+               "--flavour", str(args.flavour), "--vol-n", str(args.vol_n), "--layout", str(args.layout), "--arith", args.arith]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
         except Exception as e:  # noqa: BLE001
@@ -154,7 +155,7 @@ def live_pmc(args, passes=PMC_PASSES, timeout_s=150):
 
 
 # ------------------------------------------------------------------------------------------------ CPU oracle legs
-def oracle_legs(app, variant, vols, W, H, gpu_frame, gpu_samples, budget_s=25.0):
+def oracle_legs(app, variant, vols, W, H, gpu_frame, gpu_samples, budget_s=25.0, fused=False):
     """The CPU oracle (a port: plain-C restatement of the WGSL) on the SAME frame: all host cores on the densest
     regular pixel grid that fits the budget (the whole frame for C1-C4), compared pixel by pixel with the GPU frame,
     and one thread on a sparser grid.  Checker and reported baseline only; never part of the product path."""
@@ -163,6 +164,7 @@ def oracle_legs(app, variant, vols, W, H, gpu_frame, gpu_samples, budget_s=25.0)
     import oracle_binding as ob
     from volumerendering_amd import workloads as wl
 
+    ob.set_arithmetic(1 if fused else 0)  # the checker's mode follows the mode of the frame it checks
     cores = host_cores()
     ub, volumes, tfs = wl.oracle_inputs(app, vols)
     uo = hr.Uniforms.from_buffer_copy(ub)
@@ -226,6 +228,8 @@ def main():
     ap.add_argument("--no-regimes", action="store_true", help="skip the air x TF regime table (C3)")
     ap.add_argument("--pmc-extra", action="store_true", help="more counter passes (L1 / TA / wait states); all counters go into `pmc`")
     ap.add_argument("--flavour", type=int, default=0)
+    ap.add_argument("--arith", default="separate", choices=["separate", "fused"],
+                    help="vr_set_arithmetic for the headline legs (the other mode is timed as the `arith_ab` leg)")
     ap.add_argument("--layout", type=int, default=0, choices=[0, 1, 2],
                     help="vr_set_volume_layout: 0 density plane for .a fetches, 1 the reference's vec4 voxels only, 2 = 0 + lit "
                          "gradients derived on the fly from the plane")
@@ -278,6 +282,7 @@ def main():
     if args.flavour:
         ctx.set_kernel_flavour(args.flavour)
     ctx.set_volume_layout(args.layout)
+    ctx.set_arithmetic(1 if args.arith == "fused" else 0)
     if args.exp_mode or args.exp_steps >= 0:  # experiments only: not the BASELINE workload any more
         app.set_params(fragment_mode=args.exp_mode, steps_count=args.exp_steps)
         app.OnUpdate()
@@ -382,6 +387,25 @@ def main():
                 "kernel_ms_mean": round(float(np.mean(kt)), 4) if len(kt) else None, "kernel_events": int(len(kt))}
 
     serial, over = leg(dt_serial, kt_serial, 1), leg(dt_over, kt_over, nbuf_over)
+    # the other arithmetic mode, same scene, both legs (20 frames each; outside the K-step regions above)
+    arith_ab = None
+    if not multi:
+        other = "separate" if args.arith == "fused" else "fused"
+        ctx.set_arithmetic(1 if other == "fused" else 0)
+        dt_s2, kt_s2 = timed_leg(1, 5, 20)
+        dt_o2, kt_o2 = timed_leg(nbuf_over, 5, 20)
+        cs2, _, fs2 = ctx.counters()
+        arith_ab = {"arithmetic": other,
+                    "serial": {"ms_per_step": round(dt_s2 / 20 * 1e3, 4), "kernel_ms_median": round(float(np.median(kt_s2)), 4),
+                               "value": round(cs2 / (dt_s2 / 20) / 1e9, 3)},
+                    "overlapped": {"frames_in_flight": nbuf_over, "ms_per_step": round(dt_o2 / 20 * 1e3, 4),
+                                   "value": round(cs2 / (dt_o2 / 20) / 1e9, 3)},
+                    "composited_samples_per_frame": cs2, "fetched_samples_per_frame": fs2,
+                    "note": "vr_set_arithmetic: per-sample a*b+c with one rounding (fused) instead of two; bit-exact against the "
+                            "oracle's mode of the same name (tests/), ray placement identical in both modes"}
+        ctx.set_arithmetic(1 if args.arith == "fused" else 0)
+        ctx.render_async(variant, frames[0].data_ptr(), streams[0].cuda_stream)  # frames[0] = the headline mode's frame again
+        torch.cuda.synchronize()
     kernel_ms = serial["kernel_ms_median"]
     bs = wl.BYTES_PER_SAMPLE[vname]
     owned_px = W * H if not multi else ctx.tile_count(rank, world) * capi.TILE * capi.TILE
@@ -482,6 +506,9 @@ def main():
         },
         "serial": serial, "overlapped": over, "roofline": roofline,
     }
+    out["config"]["arithmetic"] = args.arith
+    if arith_ab:
+        out["arith_ab"] = arith_ab
     if args.pmc_extra:
         out["pmc"] = {"per": "march-kernel launch, mean of the profiled launches (one at a time), first launch dropped", **pmc}
 
@@ -505,6 +532,7 @@ def main():
                 if args.flavour:
                     ctx.set_kernel_flavour(args.flavour)
                 ctx.set_volume_layout(args.layout)
+                ctx.set_arithmetic(1 if args.arith == "fused" else 0)
             current = (air, tf)
 
         regimes = []
@@ -529,7 +557,8 @@ def main():
         scene(args.air, args.tf)  # the CPU legs below want the headline scene again
 
     if rank == 0 and world == 1 and not multi and not args.no_cpu_baseline:
-        parity, base = oracle_legs(app, variant, vols, W, H, gpu_frame, total_samples)
+        parity, base = oracle_legs(app, variant, vols, W, H, gpu_frame, total_samples, fused=(args.arith == "fused"))
+        parity["arithmetic"] = args.arith
         out["parity"] = parity
         out["cpu_baseline"] = base
     if rank == 0 and multi:
