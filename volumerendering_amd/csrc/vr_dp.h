@@ -135,14 +135,7 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
                 }
                 if constexpr (V == V_VOLUME_MASK || V == V_THREE_FILES) wstep = step;
                 w = ray.world0;
-                {
-                    const float fx = step.x > 0.0f ? (bx1 - p.x) / step.x : (step.x < 0.0f ? (bx0 - p.x) / step.x : 3.0e38f);
-                    const float fy = step.y > 0.0f ? (by1 - p.y) / step.y : (step.y < 0.0f ? (by0 - p.y) / step.y : 3.0e38f);
-                    const float fz = step.z > 0.0f ? (bz1 - p.z) / step.z : (step.z < 0.0f ? (bz0 - p.z) / step.z : 3.0e38f);
-                    const bool in0 = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
-                    const float f = fminf(fminf(fx, fy), fminf(fz, 1.0e6f)) * 0.999f - 2.0f;
-                    if (in0 && f > 0.0f) n_inside = (int)f;  // NaN / negative -> 0
-                }
+                n_inside = steps_inside(p, step, bx0, by0, bz0, bx1, by1, bz1);
                 alive = true;
             }
         }

@@ -1023,6 +1023,30 @@ __device__ __forceinline__ float leap_axis(float p, float s, float bs, int nb, i
     return room * (__builtin_amdgcn_rcpf(fabsf(s)) * 0.999f);  // approximate reciprocal, scaled down: never too large
 }
 
+
+// Number of steps a ray certainly stays inside IsInSampleCoords: positions p_0 .. p_{n-1} of the accumulation
+// p_{k+1} = fl(p_k + step) are inside [b0, b1] on every axis.
+//  - behind the ray nothing can happen: rounding is monotone, so a coordinate never moves against the sign of its step;
+//  - ahead, p_k <= p_0 + k * (|step| + e): each rounded addition errs by at most half an ulp of its result, i.e. by at most
+//    2^-24 * M with M = the largest magnitude in play (e below is 2^-23 * M: twice that).  For an axis the ray hardly moves
+//    along (|step| of the order of e) the ACCUMULATED rounding, not the step, decides when the bound is crossed -- a margin
+//    counted in steps alone is wrong there (found by tests/test_scale_gpu.py with 4 000-step rays).
+// The quotient is taken 0.1 % + 2 steps short to cover its own evaluation in f32.  NaN / negative -> 0.
+__device__ __forceinline__ float steps_inside_axis(float p, float s, float b0, float b1)
+{
+    const float e = fmaxf(fmaxf(fabsf(b0), fabsf(b1)), fabsf(p)) * 1.1920929e-7f;
+    if (s > 0.0f) return (b1 - p) / (s + e);
+    if (s < 0.0f) return (p - b0) / (e - s);
+    return 3.0e38f;  // fl(p + 0) == p: the coordinate never changes
+}
+__device__ __forceinline__ int steps_inside(f3 p, f3 step, float bx0, float by0, float bz0, float bx1, float by1, float bz1)
+{
+    const bool in0 = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
+    const float f = fminf(fminf(steps_inside_axis(p.x, step.x, bx0, bx1), steps_inside_axis(p.y, step.y, by0, by1)),
+                          fminf(steps_inside_axis(p.z, step.z, bz0, bz1), 1.0e6f)) * 0.999f - 2.0f;
+    return (in0 && f > 0.0f) ? (int)f : 0;
+}
+
 // OTF (V_LIGHT only): the corners' gradients are derived from the density plane (fetch_rgba_otf) instead of read from
 // the vec4 voxels; the host asks for it when the volume's .rgb is verified to be PreComputeGradient(false) of its .a.
 template <int V, bool OFF32, bool SKIP, int LEAP, bool OTF = false>
@@ -1070,19 +1094,8 @@ __global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
                 f3 w = ray.world0;
                 const float bx0 = P.bmin[0], by0 = P.bmin[1], bz0 = P.bmin[2];
                 const float bx1 = P.bmax[0], by1 = P.bmax[1], bz1 = P.bmax[2];
-                // Steps [0, n_inside) are certainly inside IsInSampleCoords: p moves monotonically per component
-                // (a rounded addition of a constant never moves against its sign), so the bound behind the ray
-                // holds for good once it holds at the start, and the bound ahead is far enough away by a margin
-                // (0.1 % + 2 steps) that dwarfs the accumulated rounding.  The six compares are skipped there.
-                int n_inside = 0;
-                {
-                    const float fx = step.x > 0.0f ? (bx1 - p.x) / step.x : (step.x < 0.0f ? (bx0 - p.x) / step.x : 3.0e38f);
-                    const float fy = step.y > 0.0f ? (by1 - p.y) / step.y : (step.y < 0.0f ? (by0 - p.y) / step.y : 3.0e38f);
-                    const float fz = step.z > 0.0f ? (bz1 - p.z) / step.z : (step.z < 0.0f ? (bz0 - p.z) / step.z : 3.0e38f);
-                    const bool in0 = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
-                    const float f = fminf(fminf(fx, fy), fminf(fz, 1.0e6f)) * 0.999f - 2.0f;
-                    if (in0 && f > 0.0f) n_inside = (int)f;  // NaN / negative -> 0
-                }
+                // Steps [0, n_inside) are certainly inside IsInSampleCoords (steps_inside): the six compares are skipped there.
+                const int n_inside = steps_inside(p, step, bx0, by0, bz0, bx1, by1, bz1);
                 // ---- the march loop ---------------------------------------------------------------------------------
                 // Empty-space test: one byte per brick (distance field), looked up for the positions AHEAD of the ray
                 // (the same rounded additions the advance performs, so they are the positions later iterations really
