@@ -207,6 +207,15 @@ int vr_unpack_tiles_async(vr_ctx* ctx, const void* d_gathered, int world, void* 
  * whose blend executed, summed over the pixels rendered by the last render call.                 */
 int vr_download(vr_ctx* ctx, float* frag_rgba, uint8_t* present_bgra8, uint64_t* composited_samples);
 
+/* Presentation without a host round trip.  Replaces: the output merge + swap-chain present of Application::OnRender
+ * (App/src/Application.cpp:180-233: blend SrcAlpha/OneMinusSrcAlpha over the white background quad into the BGRA8Unorm
+ * swap-chain image) for a caller that shows the frame itself: writes the presented BGRA8Unorm pixels of the device frame
+ * `d_frame` (W*H*4 floats; NULL = the ctx-owned frame of vr_render) into DEVICE memory `d_bgra8` (W*H*4 bytes) on `stream`
+ * (NULL = the ctx's own) -- e.g. a GL / Vulkan buffer or texture staging buffer imported into HIP
+ * (hipGraphicsGLRegisterBuffer + hipGraphicsResourceGetMappedPointer, or hipImportExternalMemory).  Nothing is
+ * synchronised; the same arithmetic as vr_download's present_bgra8.                                               */
+int vr_present_async(vr_ctx* ctx, const void* d_frame, void* d_bgra8, void* stream);
+
 /* Packed tiles of the last vr_render_tiles (host copy). */
 int vr_download_tiles(vr_ctx* ctx, float* tiles_rgba, uint64_t* composited_samples);
 

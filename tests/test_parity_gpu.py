@@ -724,3 +724,21 @@ def test_fused_layouts_hostile_values_and_mode_switching(fused):
     fused.set_arithmetic(capi.ARITH_FUSED)
     assert not np.array_equal(vt.bits(f_fused), vt.bits(f_sep))
     assert float(np.max(np.abs(f_fused - f_sep))) <= 1e-4
+
+
+def test_present_async_into_device_memory(ctx):
+    """vr_present_async: the BGRA8 present written on the device into caller memory (the hand-over to a GL / Vulkan
+    buffer imported into HIP), equal to the oracle's output merge and to vr_download's.  (The "caller memory" here is the
+    frame buffer of a second context: device memory this test can read back without another GPU library in the process.)"""
+    W, H = 64, 48
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(capi.LIGHT, n=16)
+    u = hr.make_uniforms(W, H, steps_count=27, step_size=1 / 16)
+    frag, bgra, _ = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs, present=True)
+    with capi.Context(W, H, 0) as other:
+        dst = other.frame_device_ptr()
+        ctx.present_async(dst)          # from the ctx-owned frame, on the ctx's own stream
+        ctx.download()                  # synchronises that stream
+        raw, _, _ = other.download()
+        got = raw.view(np.uint8).reshape(-1)[: W * H * 4].reshape(H, W, 4)
+        assert np.array_equal(got, bgra) and np.array_equal(got, ob.present(frag))

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
-    "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic",
+    "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async",
 ]
 
 
@@ -108,6 +108,7 @@ def load() -> C.CDLL:
     lib.vr_last_kernel_flavour.argtypes = [vp]
     lib.vr_set_volume_layout.argtypes = [vp, i32]
     lib.vr_set_arithmetic.argtypes = [vp, i32]
+    lib.vr_present_async.argtypes = [vp, vp, vp, vp]
     lib.vr_volume_layout.argtypes = [vp, i32, C.POINTER(C.c_int)]
     _lib = lib
     return lib
@@ -275,6 +276,10 @@ class Context:
 
     def last_kernel_flavour(self) -> int:
         return self._chk(self.lib.vr_last_kernel_flavour(self.h))
+
+    def present_async(self, d_bgra8: int, d_frame: int = 0, stream: int = 0):
+        """BGRA8Unorm present of a device frame into device memory (what a GL / Vulkan interop buffer would be)."""
+        self._chk(self.lib.vr_present_async(self.h, d_frame, d_bgra8, stream))
 
     def set_arithmetic(self, mode: int):
         """ARITH_SEPARATE (0, default) or ARITH_FUSED (1): per-sample a * b + c with two roundings or one (include/vr.h)."""

@@ -35,7 +35,7 @@ struct KernelRing {  // one (start, stop) event pair per render call, reused rou
 }  // namespace
 
 constexpr int kInFlight = 4;  // renders that may be in flight at a time (one stream and one output buffer each)
-constexpr int kOrderRing = 8;  // launch-order buffers: written behind launch k, read by launches k+1 .. k+3 only
+constexpr int kOrderRing = 8;  // launch-order buffers: written behind launch k, read by launches k+3 and k+4 only
 
 struct vr_ctx {
     int device = 0;
@@ -445,18 +445,19 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         P.block_counts = c->d_block_counts[cb];
         c->cnt_buf = cb;
-        // launch order: the most recent sort of a launch of the same shape that is two or three launches old -- not the
-        // launch just before this one, whose sort has not even started (it runs on a side stream behind that launch), and
-        // not an older one, whose buffer may be recycled under this launch; ordered behind it by its event
+        // launch order: the most recent sort of a launch of the same shape that is three or four launches old -- a younger
+        // one may still be waiting for its launch to finish (the sorts run on a side stream behind their launches; waiting
+        // for one would put a bubble into this stream), an older one's buffer may be recycled under this launch; ordered
+        // behind it by its event (long complete by then)
         const unsigned long long okey = ((unsigned long long)grid.x << 32) ^ ((unsigned long long)block.x << 20) ^
                                         ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
                                         ((unsigned long long)fl << 44) ^ (packed ? 1ull << 63 : 0ull);
         P.order = nullptr;
-        const bool ordered = c->order_mode == 1 && !wtb && grid.x <= (unsigned)kOrderMaxBlocks;
+        const bool ordered = c->order_mode == 1 && !wtb && grid.x <= (unsigned)kOrderMaxBlocks && grid.x % 8u == 0;
         if (ordered) {
             const vr_ctx::OrderSlot* best = nullptr;
             for (const auto& o : c->order_ring)
-                if (o.valid && o.key == okey && o.seq + 3 >= c->order_seq && o.seq + 2 <= c->order_seq && (!best || o.seq > best->seq))
+                if (o.valid && o.key == okey && o.seq + 4 >= c->order_seq && o.seq + 3 <= c->order_seq && (!best || o.seq > best->seq))
                     best = &o;
             if (best) {
                 VR_HIP(c, hipStreamWaitEvent(s, best->sorted, 0));
@@ -997,6 +998,20 @@ int vr_unpack_tiles_async(vr_ctx* c, const void* d_gathered, int world, void* d_
     dim3 block(64, 4), grid((c->W + 63) / 64, (c->H + 3) / 4);
     hipLaunchKernelGGL(unpack_tiles_kernel, grid, block, 0, s, (const float4*)d_gathered, frame, (int)c->W, (int)c->H,
                        tiles_x_of(c), world, tpr);
+    VR_HIP(c, hipGetLastError());
+    return VR_OK;
+}
+
+int vr_present_async(vr_ctx* c, const void* d_frame, void* d_bgra8, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!d_bgra8) return fail(c, VR_ERR_INVALID_ARG, "vr_present_async: destination is NULL");
+    VR_HIP(c, hipSetDevice(c->device));
+    (void)hipGetLastError();
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t n = (size_t)c->W * c->H;
+    hipLaunchKernelGGL(present_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       d_frame ? (const float4*)d_frame : c->d_frame, (uint32_t*)d_bgra8, (int)n);
     VR_HIP(c, hipGetLastError());
     return VR_OK;
 }

@@ -1405,33 +1405,34 @@ __global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned lo
 }
 
 // One workgroup: order[] = the logical blocks of the launch whose records are `in`, sorted by the longest per-ray sample
-// chain of the block (record word 5, bits 40..), longest first -- a counting sort over 1024 key buckets.  The next
-// frame's workgroups take their blocks in this order (MarchParams::order): longest-processing-time-first scheduling.
+// chain of the block (record word 5, bits 40..), longest first, SEPARATELY within each residue class of the block index
+// modulo 8: position b of the order holds a block lb with lb % 8 == b % 8.  Workgroups are dispatched round-robin over the
+// 8 XCDs, so a block stays on the XCD its index maps to (what map_pixel's xcd_mode relies on) and every XCD runs its own
+// blocks longest-processing-time-first.  Eight counting sorts over 128 key buckets each (n_blocks % 8 == 0).
 constexpr int kOrderMaxBlocks = 32 * 1024;  // launches with more blocks keep the index order
 __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long long* __restrict__ in, int n_blocks,
                                                             unsigned* __restrict__ order)
 {
-    __shared__ unsigned hist[1024];
+    __shared__ unsigned hist[1024];  // [class 0..7][bucket 0..127]
     __shared__ unsigned base[1024];
-    __shared__ unsigned wave_total[16];
     const int t = threadIdx.x;
     hist[t] = 0;
     __syncthreads();
     // every record is read ONCE (a launch that recycles the record buffer under this kernel can then only change the
-    // order, never make it something other than a permutation); bucket 0 = the longest chains
+    // order, never make it something other than a permutation); bucket 0 = the longest chains (32 steps per bucket)
     unsigned short bk[kOrderMaxBlocks / 1024];
 #pragma unroll
     for (int k = 0; k < kOrderMaxBlocks / 1024; ++k) {
         const int b = t + k * 1024;
         if (b < n_blocks) {
             const unsigned long long crit = in[(size_t)b * kBlockRecord + 5] >> 40;
-            const unsigned q = (unsigned)(crit >> 2);
-            bk[k] = (unsigned short)(1023u - (q > 1023u ? 1023u : q));
+            const unsigned q = (unsigned)(crit >> 5);
+            bk[k] = (unsigned short)(((unsigned)b & 7u) * 128u + (127u - (q > 127u ? 127u : q)));
             atomicAdd(&hist[bk[k]], 1u);
         }
     }
     __syncthreads();
-    {   // exclusive prefix sum of the 1024 bucket counts: wave scan, then the 16 wave totals
+    {   // exclusive prefix sum inside each class: classes are 128 consecutive entries = two wavefronts
         const unsigned mine = hist[t];
         unsigned incl = mine;
 #pragma unroll
@@ -1439,18 +1440,18 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
             const unsigned up = (unsigned)__shfl_up((int)incl, off, 64);
             if ((t & 63) >= off) incl += up;
         }
+        __shared__ unsigned wave_total[16];
         if ((t & 63) == 63) wave_total[t >> 6] = incl;
         __syncthreads();
-        unsigned before = 0;
-        for (int w = 0; w < (t >> 6); ++w) before += wave_total[w];
+        const unsigned before = ((t >> 6) & 1) ? wave_total[(t >> 6) - 1] : 0u;  // the class's first wavefront
         base[t] = before + incl - mine;
     }
     __syncthreads();
-    // scatter with one cursor per bucket (the order inside a bucket does not matter)
+    // scatter with one cursor per (class, bucket): the i-th block of class x goes to position 8 * i + x
 #pragma unroll
     for (int k = 0; k < kOrderMaxBlocks / 1024; ++k) {
         const int b = t + k * 1024;
-        if (b < n_blocks) order[atomicAdd(&base[bk[k]], 1u)] = (unsigned)b;
+        if (b < n_blocks) order[8u * atomicAdd(&base[bk[k]], 1u) + ((unsigned)b & 7u)] = (unsigned)b;
     }
 }
 
