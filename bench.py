@@ -58,10 +58,10 @@ KERNEL_OF_FLAVOUR = {1: "march_kernel (no skipping)", 2: "march_wtb_light_kernel
 
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"],
-              ["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"]]
+              ["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"], ["TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"]]
 
 
-PMC_EXTRA = [["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"], ["TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum"],
+PMC_EXTRA = [["TCP_PENDING_STALL_CYCLES_sum"],
              ["SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_INST_CYCLES_VMEM", "SQ_INSTS_SALU", "SQ_INSTS_LDS"],
              ["SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT"]]
 
@@ -466,7 +466,28 @@ def main():
             "busy_frac": round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * cyc), 4),
             "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of the launch's SIMD-cycles "
                     "spent issuing vector ALU work (serial, profiled launches)"}
-        roofline["limiter"] = "valu-issue + longest-ray tail" if roofline["valu"]["busy_frac"] > (roofline["frac"] or 0) else "hbm"
+        clock_hz = cyc / (kernel_ms * 1e-3) if kernel_ms else None  # effective shader clock of the profiled launches
+        over_cyc = over["ms_per_step"] * 1e-3 * clock_hz if clock_hz else None
+        roofline["valu"]["busy_frac_overlapped"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * over_cyc), 4) if over_cyc else None
+        roofline["valu"]["clock_ghz"] = round(clock_hz / 1e9, 3) if clock_hz else None
+        # the vector-memory (texture addresser / L1) data path: every lane's bytes are returned at 64 B / clk / CU
+        tf_bytes = {"BASIC": 40, "LIGHT": 40, "LIGHT_INSHADER": 40, "TF_CALIB": 40}.get(vname, 80)
+        l1_bytes = my_fetched * (bs + tf_bytes) + my_samples // 1  # + one distance-field byte per executed step (lower bound)
+        l1_peak = 64.0 * 256 * clock_hz / 1e9 if clock_hz else None
+        roofline["l1"] = {
+            "bytes_per_launch": l1_bytes, "peak_gbs": round(l1_peak, 1) if l1_peak else None,
+            "achieved_gbs": round(l1_bytes / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms else None,
+            "frac": round(l1_bytes / (kernel_ms * 1e-3) / 1e9 / l1_peak, 4) if (l1_peak and kernel_ms) else None,
+            "frac_overlapped": round(l1_bytes / (over["ms_per_step"] * 1e-3) / 1e9 / l1_peak, 4) if l1_peak else None,
+            "ta_busy_frac": round(pmc["TA_BUSY_avr"] / cyc, 4) if "TA_BUSY_avr" in pmc else None,
+            "ta_busy_frac_overlapped": round(pmc["TA_BUSY_avr"] / over_cyc, 4) if ("TA_BUSY_avr" in pmc and over_cyc) else None,
+            "note": "bytes the lanes receive from L1 (corner voxels + transfer-function texels of every fetched sample) against the "
+                    "64 B/clk/CU return path of the vector memory pipeline at the measured clock; TA_BUSY_avr = busy cycles of the "
+                    "texture addressers per launch"}
+        fr = {"hbm": roofline["frac_overlapped"] or 0, "valu-issue": roofline["valu"]["busy_frac_overlapped"] or 0,
+              "l1-return-path": roofline["l1"]["ta_busy_frac_overlapped"] or roofline["l1"]["frac_overlapped"] or 0}
+        roofline["limiter"] = max(fr, key=fr.get) + " (throughput leg); longest-ray tail on top of it in the serial leg"
+        roofline["limiter_fractions_overlapped"] = fr
     if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
         roofline["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
     # second denominator: what a plain device-to-device copy reaches on this GPU right now
