@@ -149,6 +149,16 @@ def live_pmc(args, passes=PMC_PASSES, timeout_s=150):
             for name, dd in per.items():
                 vals = [dd[k] for k in sorted(dd)][1:] or list(dd.values())  # drop the first (cold) launch
                 out[name] = sum(vals) / len(vals)
+        # duration of the PROFILED march launches of this pass (they run slower than un-profiled ones: counters are only
+        # comparable with a time base taken under the same profiler)
+        if "GRBM_GUI_ACTIVE" in ctrs:
+            for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    durs = [(int(r["Dispatch_Id"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                            for r in csv.DictReader(fh) if "march" in r["Kernel_Name"]]
+                durs = [x[1] for x in sorted(durs)][1:]
+                if durs:
+                    out["_profiled_march_ms"] = sum(durs) / len(durs) / 1e6
     if not keep:
         shutil.rmtree(tmp, ignore_errors=True)
     return out, note
@@ -466,7 +476,10 @@ def main():
             "busy_frac": round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * cyc), 4),
             "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of the launch's SIMD-cycles "
                     "spent issuing vector ALU work (serial, profiled launches)"}
-        clock_hz = cyc / (kernel_ms * 1e-3) if kernel_ms else None  # effective shader clock of the profiled launches
+        # effective shader clock: cycles of the profiled launches over THEIR duration (kernel trace of the same pass)
+        prof_ms = pmc.get("_profiled_march_ms")
+        clock_hz = cyc / (prof_ms * 1e-3) if prof_ms else None
+        roofline["valu"]["profiled_kernel_ms"] = round(prof_ms, 4) if prof_ms else None
         over_cyc = over["ms_per_step"] * 1e-3 * clock_hz if clock_hz else None
         roofline["valu"]["busy_frac_overlapped"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * over_cyc), 4) if over_cyc else None
         roofline["valu"]["clock_ghz"] = round(clock_hz / 1e9, 3) if clock_hz else None
@@ -531,7 +544,8 @@ def main():
     if arith_ab:
         out["arith_ab"] = arith_ab
     if args.pmc_extra:
-        out["pmc"] = {"per": "march-kernel launch, mean of the profiled launches (one at a time), first launch dropped", **pmc}
+        out["pmc"] = {"per": "march-kernel launch, mean of the profiled launches (one at a time), first launch dropped",
+                      **{k: v for k, v in pmc.items() if not k.startswith("_")}}
 
     # ---- the regime table (C3): {exact-0 air, noisy air} x {default ramp, zero-prefix TF}, serial leg -------------
     if rank == 0 and not multi and args.workload == "C3" and not args.no_regimes and not args.vol_n:
