@@ -99,7 +99,7 @@ struct vr_ctx {
     Timing tm;
     KernelRing ring;
     int flavour = 0;
-    int waves_per_block = 4;  // 1 or 4 (experiment knob VR_EXP_WAVES_PER_BLOCK)
+    int waves_per_block = 1;  // 1 (default: the launch order of section 4.6 works at wavefront granularity) or 4 (VR_EXP_WAVES_PER_BLOCK)
     int only_tile = -1;       // experiment knob VR_EXP_ONLY_TILE
     int prio_mode = 0;        // VR_EXP_PRIO=1: wave priority by remaining ray path (+2-3 % for one frame at a time,
                               // -2 % with frames in flight, where nothing waits for the long rays)
@@ -748,7 +748,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->n_cus = cus;
     }
     // experiment knobs (A/B measurements; none changes any result)
-    if (const char* e = getenv("VR_EXP_WAVES_PER_BLOCK")) c->waves_per_block = (atoi(e) == 1) ? 1 : 4;
+    if (const char* e = getenv("VR_EXP_WAVES_PER_BLOCK")) c->waves_per_block = (atoi(e) == 4) ? 4 : 1;
     if (const char* e = getenv("VR_EXP_ONLY_TILE")) c->only_tile = atoi(e);
     if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_FLAVOUR")) c->default_flavour = atoi(e);

@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned lo
 // modulo 8: position b of the order holds a block lb with lb % 8 == b % 8.  Workgroups are dispatched round-robin over the
 // 8 XCDs, so a block stays on the XCD its index maps to (what map_pixel's xcd_mode relies on) and every XCD runs its own
 // blocks longest-processing-time-first.  Eight counting sorts over 128 key buckets each (n_blocks % 8 == 0).
-constexpr int kOrderMaxBlocks = 32 * 1024;  // launches with more blocks keep the index order
+constexpr int kOrderMaxBlocks = 192 * 1024;  // launches with more blocks keep the index order (C5, one wavefront per block: 130 560)
 __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long long* __restrict__ in, int n_blocks,
                                                             unsigned* __restrict__ order)
 {
@@ -1420,9 +1420,8 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
     __syncthreads();
     // every record is read ONCE (a launch that recycles the record buffer under this kernel can then only change the
     // order, never make it something other than a permutation); bucket 0 = the longest chains (32 steps per bucket)
-    unsigned short bk[kOrderMaxBlocks / 1024];
-#pragma unroll
-    for (int k = 0; k < kOrderMaxBlocks / 1024; ++k) {
+    unsigned short bk[kOrderMaxBlocks / 1024];  // (private memory: the loops are not unrolled)
+    for (int k = 0; k * 1024 < n_blocks; ++k) {
         const int b = t + k * 1024;
         if (b < n_blocks) {
             const unsigned long long crit = in[(size_t)b * kBlockRecord + 5] >> 40;
@@ -1448,8 +1447,7 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
     }
     __syncthreads();
     // scatter with one cursor per (class, bucket): the i-th block of class x goes to position 8 * i + x
-#pragma unroll
-    for (int k = 0; k < kOrderMaxBlocks / 1024; ++k) {
+    for (int k = 0; k * 1024 < n_blocks; ++k) {
         const int b = t + k * 1024;
         if (b < n_blocks) order[8u * atomicAdd(&base[bk[k]], 1u) + ((unsigned)b & 7u)] = (unsigned)b;
     }
