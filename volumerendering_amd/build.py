@@ -35,7 +35,7 @@ def build_hip(force: bool = False) -> str:
     target = os.path.join(HERE, "libvr_hip.so")
     hdrs = [os.path.join(CSRC, f) for f in ("vr_kernels.h", "vr_wtb.h", "vr_dp.h", "vr_device.h", "vr_launch.h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "vr.h"))
-    flags = [f for f in HIP_FLAGS if f != "-shared"]
+    flags = [f for f in HIP_FLAGS if f != "-shared"] + os.environ.get("VR_EXTRA_HIPCC_FLAGS", "").split()
     objs, procs = [], []
     for name in ("vr_api", "vr_fused"):
         src, obj = os.path.join(CSRC, name + ".hip"), os.path.join(CSRC, name + ".o")

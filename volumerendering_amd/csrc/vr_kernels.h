@@ -31,6 +31,12 @@
 #ifndef VR_FUSED
 #define VR_FUSED 0
 #endif
+// Experiment knob (build with -DVR_LIGHT_WPE=6): ask the compiler for six waves per SIMD for the lit one-lane kernel (80
+// VGPRs instead of 88-90) at the price of a few spilled registers.
+#ifndef VR_LIGHT_WPE
+#define VR_LIGHT_WPE 1
+#endif
+#define VR_LIGHT_WAVES_PER_EU(V, OTF) (((V) == 1 && !(OTF)) ? VR_LIGHT_WPE : 1)
 
 namespace VR_KNS {
 using namespace vr;
@@ -1050,7 +1056,7 @@ __device__ __forceinline__ int steps_inside(f3 p, f3 step, float bx0, float by0,
 // OTF (V_LIGHT only): the corners' gradients are derived from the density plane (fetch_rgba_otf) instead of read from
 // the vec4 voxels; the host asks for it when the volume's .rgb is verified to be PreComputeGradient(false) of its .a.
 template <int V, bool OFF32, bool SKIP, int LEAP, bool OTF = false>
-__global__ __launch_bounds__(256) void march_kernel(const MarchParams P)
+__global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kernel(const MarchParams P)
 {
     const unsigned long long t_start = wall_clock64();
     PixelSlot slot = map_pixel(P);
