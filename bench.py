@@ -301,9 +301,10 @@ def main():
     tpr_max = ctx.tile_count(0, world)
     tile_floats = capi.TILE * capi.TILE * 4
     max_flight = 2 if multi else max(2, args.in_flight)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max_flight - 1)]
-    for st in streams[1:]:
-        st.wait_stream(streams[0])
+    # context-owned streams probed to really run side by side (two arbitrary HIP streams may share a hardware queue and
+    # serialise: vr_stream, include/vr.h)
+    streams = [ctx.stream(i) for i in range(max_flight)]
+    torch.cuda.synchronize()
     frames = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(max_flight)] if not multi else []
     mg = None
     if multi and backend == "rccl":
@@ -325,7 +326,7 @@ def main():
     def run_frames(n_frames, nbuf):
         if not multi:
             for k in range(n_frames):
-                ctx.render_async(variant, frames[k % nbuf].data_ptr(), streams[k % nbuf].cuda_stream)
+                ctx.render_async(variant, frames[k % nbuf].data_ptr(), streams[k % nbuf])
             return
         if mg is not None:
             # the C++ loop: every rank renders its tiles, ncclGather, the root un-permutes; two buffer sets, so up to two
@@ -338,12 +339,12 @@ def main():
             return
         for k in range(n_frames):  # gloo rehearsal: synchronous, through host memory
             b = k & 1
-            ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), streams[0].cuda_stream)
+            ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), streams[0])
             host_list = [torch.empty(my_tiles[b].numel()) for _ in range(world)] if rank == 0 else None
             dist.gather(my_tiles[b].cpu(), host_list, dst=0)
             if rank == 0:
                 gathered[b].copy_(torch.stack(host_list))
-                ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames[b].data_ptr(), streams[0].cuda_stream)
+                ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames[b].data_ptr(), streams[0])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -414,7 +415,7 @@ def main():
                     "note": "vr_set_arithmetic: per-sample a*b+c with one rounding (fused) instead of two; bit-exact against the "
                             "oracle's mode of the same name (tests/), ray placement identical in both modes"}
         ctx.set_arithmetic(1 if args.arith == "fused" else 0)
-        ctx.render_async(variant, frames[0].data_ptr(), streams[0].cuda_stream)  # frames[0] = the headline mode's frame again
+        ctx.render_async(variant, frames[0].data_ptr(), streams[0])  # frames[0] = the headline mode's frame again
         torch.cuda.synchronize()
     kernel_ms = serial["kernel_ms_median"]
     bs = wl.BYTES_PER_SAMPLE[vname]
@@ -575,11 +576,11 @@ def main():
             for tf in ("default", "prefix"):
                 scene(air, tf)
                 for _ in range(3):
-                    ctx.render_async(variant, frames[1].data_ptr(), streams[0].cuda_stream)
+                    ctx.render_async(variant, frames[1].data_ptr(), streams[0])
                 torch.cuda.synchronize()
                 ctx.reset_kernel_times()
                 for _ in range(20):
-                    ctx.render_async(variant, frames[1].data_ptr(), streams[0].cuda_stream)
+                    ctx.render_async(variant, frames[1].data_ptr(), streams[0])
                 torch.cuda.synchronize()
                 ms = float(np.median(ctx.kernel_times(20)))
                 cs, _, fs = ctx.counters()

@@ -191,6 +191,13 @@ int vr_tile_count(const vr_ctx* ctx, int rank, int world);
  * vr_tf_upload*, vr_resize and vr_destroy drain the whole device first, so they are safe to call
  * while asynchronous renders are still in flight on the caller's streams.                          */
 int vr_render_async(vr_ctx* ctx, int variant, void* d_frame, void* stream);
+
+/* Streams for frames in flight.  HIP maps streams onto a few hardware queues, and two streams that share a queue run
+ * their kernels one after the other -- two frames "in flight" on such a pair gain nothing (measured: 0.60 instead of 0.48 ms
+ * per C3 frame).  vr_stream(ctx, i), i = 0..3, returns context-owned streams (hipStream_t) that were probed, on first use,
+ * to really run side by side (two 150 us single-wavefront kernels; ~3 ms once); fewer than four may exist, then the index
+ * wraps.  Use them in turn for vr_render_async / vr_render_tiles_async; NULL on failure.                              */
+void* vr_stream(vr_ctx* ctx, int index);
 int vr_render_tiles_async(vr_ctx* ctx, int variant, int rank, int world, void* d_tiles, void* stream);
 
 /* Root side of the gather: `d_gathered` holds, for r = 0..world-1, rank r's packed tiles, each

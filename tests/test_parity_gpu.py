@@ -742,3 +742,29 @@ def test_present_async_into_device_memory(ctx):
         raw, _, _ = other.download()
         got = raw.view(np.uint8).reshape(-1)[: W * H * 4].reshape(H, W, 4)
         assert np.array_equal(got, bgra) and np.array_equal(got, ob.present(frag))
+
+
+def test_context_streams_for_frames_in_flight(ctx):
+    """vr_stream: context-owned streams probed to run side by side; frames rendered on them in turn, four in flight, into the
+    buffers of four other contexts, are all bit-equal to the synchronous render."""
+    W, H = 160, 120
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(capi.LIGHT, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
+    ref, _, n_ref = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+    ss = [ctx.stream(i) for i in range(4)]
+    assert all(ss) and len(set(ss)) >= 2          # at least two distinct streams that overlap
+    assert ctx.stream(0) == ss[0]                  # stable handles
+    others = [capi.Context(W, H, 0) for _ in range(4)]
+    try:
+        for k in range(12):
+            ctx.render_async(capi.LIGHT, others[k % 4].frame_device_ptr(), ss[k % 4])
+        assert ctx.counters()[0] == n_ref         # waits for the last launch
+        ctx.resize(W, H)                          # drains the device
+        for o in others:
+            got, _, _ = o.download()
+            assert np.array_equal(vt.bits(got), vt.bits(ref))
+    finally:
+        for o in others:
+            o.close()

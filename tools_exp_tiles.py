@@ -24,11 +24,10 @@ def main():
     a = ap.parse_args()
     import torch  # first: torch's HIP runtime has to initialise before libvr_hip.so's
     torch.cuda.init()
-    import bench
-    from volumerendering_amd import capi, host, synth
-    n, W, H, vname = bench.WORKLOADS[a.workload]
+    from volumerendering_amd import capi, host, workloads as wl
+    n, W, H, vname = wl.WORKLOADS[a.workload]
     app = host.Application(W, H, 0)
-    variant, vols = bench.build_scene(app, host, synth, capi, a.workload, a.tf)
+    variant, vols = wl.build_scene(app, a.workload, a.tf)
     ctx = app.context()
     streams = [torch.cuda.Stream() for _ in range(4)]
     for fl in [int(x) for x in a.flavours.split(",")]:

@@ -80,7 +80,9 @@ int setup_rank(vr_mgpu* m, Rank& k)
 {
     MG_HIP(m, hipSetDevice(k.device));
     for (int b = 0; b < kSlots; ++b) {
-        MG_HIP(m, hipStreamCreateWithFlags(&k.s_render[b], hipStreamNonBlocking));
+        // the context's own streams: probed to really run side by side (two arbitrary streams may share a hardware queue)
+        k.s_render[b] = (hipStream_t)vr_stream(k.ctx, b);
+        if (!k.s_render[b]) return fail(m, VR_ERR_HIP, "vr_stream: no render stream available");
         MG_HIP(m, hipEventCreateWithFlags(&k.ev_render[b], hipEventDisableTiming));
         MG_HIP(m, hipEventCreateWithFlags(&k.ev_done[b], hipEventDisableTiming));
         MG_HIP(m, hipMalloc(&k.tiles[b], (m->seg_floats ? m->seg_floats : 4) * sizeof(float)));
@@ -91,7 +93,11 @@ int setup_rank(vr_mgpu* m, Rank& k)
             MG_HIP(m, hipMemset(k.frame[b], 0, (size_t)m->W * m->H * 4 * sizeof(float)));
         }
     }
-    MG_HIP(m, hipStreamCreateWithFlags(&k.s_comm, hipStreamNonBlocking));
+    {   // gather + un-permute are short and every frame waits for them: highest priority the device offers
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        MG_HIP(m, hipStreamCreateWithPriority(&k.s_comm, hipStreamNonBlocking, greatest));
+    }
     MG_HIP(m, hipMalloc(&k.d_red, 4 * sizeof(unsigned long long)));
     MG_HIP(m, hipDeviceSynchronize());
     return VR_OK;
@@ -203,7 +209,7 @@ void vr_mgpu_destroy(vr_mgpu* m)
         (void)hipDeviceSynchronize();
         if (k.comm) (void)ncclCommDestroy(k.comm);
         for (int b = 0; b < kSlots; ++b) {
-            if (k.s_render[b]) (void)hipStreamDestroy(k.s_render[b]);
+            // (s_render[] belong to the context)
             if (k.ev_render[b]) (void)hipEventDestroy(k.ev_render[b]);
             if (k.ev_done[b]) (void)hipEventDestroy(k.ev_done[b]);
             if (k.tiles[b]) (void)hipFree(k.tiles[b]);

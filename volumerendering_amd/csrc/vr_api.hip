@@ -89,6 +89,8 @@ struct vr_ctx {
         bool valid = false;
     } order_ring[kOrderRing];
     unsigned long long order_seq = 0;
+    hipStream_t flight[kInFlight] = {};  // vr_stream(): streams probed to run side by side (created on first use)
+    int n_flight = 0;
     hipStream_t order_stream = nullptr;  // the sorts run here, behind their launch's event: never on a frame's critical path
     int order_mode = 1;  // 0 = launch the blocks in index order (VR_EXP_ORDER=0)
     unsigned launch_seq = 0;
@@ -824,6 +826,7 @@ void vr_destroy(vr_ctx* c)
         if (o.buf) (void)hipFree(o.buf);
     }
     if (c->order_stream) (void)hipStreamDestroy(c->order_stream);
+    for (int k = 0; k < c->n_flight; ++k) (void)hipStreamDestroy(c->flight[k]);
     if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
     if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);
     if (c->tm.ev_k1) (void)hipEventDestroy(c->tm.ev_k1);
@@ -1142,6 +1145,48 @@ int vr_last_kernel_flavour(vr_ctx* c)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     return c->last_flavour;
+}
+
+// true if kernels enqueued on a and b run concurrently (two 150 us single-wavefront spins take ~150 us, not ~300)
+static bool streams_overlap(vr_ctx* c, hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1)
+{
+    const unsigned long long ticks = 15000;  // 150 us of the 100 MHz clock
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    (void)hipEventRecord(e0, a);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks, (unsigned*)nullptr);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks, (unsigned*)nullptr);
+    (void)hipEventRecord(e1, b);
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return true;  // cannot tell: assume the best
+    return ms < 0.24f;
+}
+
+void* vr_stream(vr_ctx* c, int index)
+{
+    if (!c || index < 0 || index >= kInFlight) return nullptr;
+    if (c->n_flight == 0) {
+        if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+        (void)hipGetLastError();
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return nullptr;
+        // candidates are created one by one; one is kept if it overlaps with every stream kept so far (at most 12 tries)
+        for (int tries = 0; tries < 12 && c->n_flight < kInFlight; ++tries) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+            bool ok = true;
+            for (int k = 0; k < c->n_flight && ok; ++k) ok = streams_overlap(c, c->flight[k], s, e0, e1);
+            if (ok) c->flight[c->n_flight++] = s;
+            else (void)hipStreamDestroy(s);  // shares a hardware queue with a kept one
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipGetLastError();
+        if (c->n_flight == 0) return nullptr;
+    }
+    return (void*)c->flight[index % c->n_flight];
 }
 
 int vr_set_arithmetic(vr_ctx* c, int mode)

@@ -1410,6 +1410,19 @@ __global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned lo
     if (threadIdx.x < 3) out[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
+// One wavefront that stays busy for `ticks` of the 100 MHz clock (bounded): vr_stream()'s probe for streams that really
+// run side by side (HIP maps streams onto a few hardware queues; two streams on one queue serialise).
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks, unsigned* __restrict__ sink)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned n = 0;
+    while (wall_clock64() - t0 < ticks && n < 4000000u) {
+        __builtin_amdgcn_s_sleep(8);
+        ++n;
+    }
+    if (sink && threadIdx.x == 0 && n == 0xFFFFFFFFu) *sink = n;  // (never true: keeps the loop observable)
+}
+
 // One workgroup: order[] = the logical blocks of the launch whose records are `in`, sorted by the longest per-ray sample
 // chain of the block (record word 5, bits 40..), longest first, SEPARATELY within each residue class of the block index
 // modulo 8: position b of the order holds a block lb with lb % 8 == b % 8.  Workgroups are dispatched round-robin over the
