@@ -10,6 +10,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-live-pmc --no-regimes --steps 20 --warmup 3 > $OUT/trace_bench.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; }
 echo "trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- python3 $R/bench.py --no-cpu-baseline --no-live-pmc --no-regimes --steps 40 --warmup 5 --in-flight 1 > $OUT/trace_serial_bench.json 2> $OUT/trace_serial.err || { echo "serial trace failed"; tail -5 $OUT/trace_serial.err; }
+echo "serial trace done"
 cd $R
 B="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-regimes --pmc-extra"
 $B > $OUT/c3_default.json 2> $OUT/c3_default.err; echo "c3 default rc $?"
@@ -19,6 +21,8 @@ $B --air noisy --layout 1 > $OUT/c3_noisy_vec4.json 2> $OUT/c3_noisy_vec4.err; e
 $B --air noisy --layout 2 > $OUT/c3_noisy_otf.json 2> $OUT/c3_noisy_otf.err; echo "c3 noisy otf rc $?"
 $B --layout 2 > $OUT/c3_otf.json 2> $OUT/c3_otf.err; echo "c3 otf rc $?"
 $B --tf thin > $OUT/c3_thin.json 2> $OUT/c3_thin.err; echo "c3 thin rc $?"
+$B --air noisy --flavour 2 > $OUT/c3_noisy_wtb.json 2> $OUT/c3_noisy_wtb.err; echo "c3 noisy wtb rc $?"
+VR_EXP_WAVES_PER_BLOCK=4 $B > $OUT/c3_wpb4.json 2> $OUT/c3_wpb4.err; echo "c3 wpb4 rc $?"
 VR_EXP_ORDER=0 $B > $OUT/c3_noorder.json 2> $OUT/c3_noorder.err; echo "c3 noorder rc $?"
 for W in C1 C2 C4 C5; do
   python3 bench.py --workload $W --steps 50 --warmup 5 --no-regimes > $OUT/${W}_default.json 2> $OUT/${W}_default.err; echo "$W rc $?"
