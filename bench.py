@@ -569,6 +569,7 @@ def main():
                     ctx.set_kernel_flavour(args.flavour)
                 ctx.set_volume_layout(args.layout)
                 ctx.set_arithmetic(1 if args.arith == "fused" else 0)
+                streams[:] = [ctx.stream(i) for i in range(max_flight)]  # the streams belong to the context
             current = (air, tf)
 
         regimes = []

@@ -427,8 +427,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         c->last_otf = otf;
         const bool dp_pipe = fl == 10 || fl == 11;  // ... with the next round's corner loads software-pipelined  // lanes per ray (vr_dp.h): 64 / 32 workgroups per tile
         const int wpb = wtb ? 4 : c->waves_per_block;
-        dim3 block((unsigned)(dp ? 256 : 64 * wpb));
-        dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 64 : 32) : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel
+        dim3 block((unsigned)(64 * wpb));
+        dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 256 : 128) / wpb : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel / map_pixel_dp
         const int cb = (int)(c->launch_seq++ % (unsigned)kInFlight);
         // the slot's previous launch (kInFlight launches ago, possibly on another stream) must have finished before its
         // record buffer is written again or re-allocated: this is what bounds the launches in flight to kInFlight

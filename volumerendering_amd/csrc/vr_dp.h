@@ -40,14 +40,19 @@ template <int K>
 __device__ __forceinline__ PixelSlot map_pixel_dp(const MarchParams& P)
 {
     PixelSlot s;
-    constexpr int kBpt = (K == 4) ? 64 : 32;  // workgroups per tile
-    const int lb = logical_block(P);
-    const int n = lb / kBpt;          // ordinal of the owned tile this block works on
-    const int sub = lb % kBpt;
+    // A tile is 256 (K = 4) or 128 (K = 2) wavefront packets; a workgroup is 1 or 4 of them (blockDim.x 64 / 256).  Packets
+    // are numbered through the launch, four consecutive ones forming the 8x8 (K = 4) / 16x8 (K = 2) pixel group the
+    // 256-thread workgroup used to be, so the pixel <-> lane mapping does not depend on the workgroup size.
+    constexpr int kPpt = (K == 4) ? 256 : 128;  // packets per tile
+    const int wpb = (int)(blockDim.x >> 6);
+    const int pk = logical_block(P) * wpb + (int)(threadIdx.x >> 6);
+    const int n = pk / kPpt;                   // ordinal of the owned tile this packet belongs to
+    const int w = pk % kPpt;
+    const int sub = w >> 2, wave = w & 3;
     const bool in_launch = n < P.n_tiles;
     const int t = P.rank + n * P.world;
     const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
-    const int wave = threadIdx.x >> 6, ray = (threadIdx.x & 63) / K;
+    const int ray = (int)(threadIdx.x & 63) / K;
     int tpx, tpy;  // pixel inside the tile
     if constexpr (K == 4) {
         tpx = ((sub & 7) << 3) + ((wave & 1) << 2) + (ray & 3);

@@ -39,10 +39,10 @@ void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, 
 }
 
 template <int V, int K, bool PIPE>
-void launch_dp(bool off32, dim3 grid, hipStream_t s, const MarchParams& P)
+void launch_dp(bool off32, dim3 grid, dim3 block, hipStream_t s, const MarchParams& P)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
-#define VR_LAUNCH_DP(O, S) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K, PIPE>), grid, dim3(256), 0, s, P)
+#define VR_LAUNCH_DP(O, S) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K, PIPE>), grid, block, 0, s, P)
     if constexpr (kCanSkip) {
         if (P.brick_dist) {
             if (off32) VR_LAUNCH_DP(true, true);
@@ -74,27 +74,27 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchParams& P)
 #endif
         if (dp == 4) {
             switch (variant) {
-            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4, false>(off32, grid, s, P); break;
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4, false>(off32, grid, block, s, P); break;
             case VR_VARIANT_LIGHT:
-                if (dp_pipe) launch_dp<V_LIGHT, 4, true>(off32, grid, s, P);
-                else launch_dp<V_LIGHT, 4, false>(off32, grid, s, P);
+                if (dp_pipe) launch_dp<V_LIGHT, 4, true>(off32, grid, block, s, P);
+                else launch_dp<V_LIGHT, 4, false>(off32, grid, block, s, P);
                 break;
-            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4, false>(off32, grid, s, P); break;
-            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4, false>(off32, grid, s, P); break;
-            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4, false>(off32, grid, s, P); break;
-            default: launch_dp<V_TF_CALIB, 4, false>(off32, grid, s, P); break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4, false>(off32, grid, block, s, P); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4, false>(off32, grid, block, s, P); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4, false>(off32, grid, block, s, P); break;
+            default: launch_dp<V_TF_CALIB, 4, false>(off32, grid, block, s, P); break;
             }
         } else if (dp == 2) {
             switch (variant) {
-            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2, false>(off32, grid, s, P); break;
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2, false>(off32, grid, block, s, P); break;
             case VR_VARIANT_LIGHT:
-                if (dp_pipe) launch_dp<V_LIGHT, 2, true>(off32, grid, s, P);
-                else launch_dp<V_LIGHT, 2, false>(off32, grid, s, P);
+                if (dp_pipe) launch_dp<V_LIGHT, 2, true>(off32, grid, block, s, P);
+                else launch_dp<V_LIGHT, 2, false>(off32, grid, block, s, P);
                 break;
-            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2, false>(off32, grid, s, P); break;
-            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2, false>(off32, grid, s, P); break;
-            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2, false>(off32, grid, s, P); break;
-            default: launch_dp<V_TF_CALIB, 2, false>(off32, grid, s, P); break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2, false>(off32, grid, block, s, P); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2, false>(off32, grid, block, s, P); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2, false>(off32, grid, block, s, P); break;
+            default: launch_dp<V_TF_CALIB, 2, false>(off32, grid, block, s, P); break;
             }
         } else
         switch (variant) {
