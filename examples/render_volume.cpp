@@ -64,7 +64,7 @@ int main(int argc, char** argv)
     }
     double sum = 0.0;
     for (float v : frag) sum += v;
-    std::printf("%s %d^3 %ux%u: %llu composited samples, sum of the fragment outputs %.9g\n", lit ? "lit" : "unlit", n, W, H,
+    std::printf("%s %d^3 %ux%u: %llu composited samples, sum of the fragment outputs %.15g\n", lit ? "lit" : "unlit", n, W, H,
                 (unsigned long long)samples, sum);
     return 0;
 }

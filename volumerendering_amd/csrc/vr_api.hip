@@ -426,7 +426,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                          !wtb && dp == 0;
         c->last_otf = otf;
         const bool dp_pipe = fl == 10 || fl == 11;  // ... with the next round's corner loads software-pipelined  // lanes per ray (vr_dp.h): 64 / 32 workgroups per tile
-        const int wpb = wtb ? 4 : c->waves_per_block;
+        // one wavefront per workgroup (launch order at wavefront granularity) -- except for the depth-parallel kernels on
+        // large launches, where 4x the workgroups cost more at dispatch than the finer order gains (C2: 32 768 workgroups of
+        // a 0.12 ms frame)
+        int wpb = wtb ? 4 : c->waves_per_block;
+        if (dp && P.n_tiles * (dp == 4 ? 256 : 128) > 16384) wpb = 4;
         dim3 block((unsigned)(64 * wpb));
         dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 256 : 128) / wpb : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel / map_pixel_dp
         const int cb = (int)(c->launch_seq++ % (unsigned)kInFlight);
