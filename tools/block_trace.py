@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Load-balance analysis of one march launch from the per-workgroup trace (vr_last_block_trace):
 
-    python tools_block_trace.py [bench.py scene args: --workload C3 --tf thin --flavour N] > gpurun_out/trace.txt
+    python tools/block_trace.py [bench.py scene args: --workload C3 --tf thin --flavour N] > gpurun_out/trace.txt
 
 Prints, per XCD and for the whole device: the span (first start .. last end), the summed workgroup time, the
 time-averaged number of resident workgroups, and how the workgroup durations are distributed."""
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
@@ -23,11 +23,10 @@ def main():
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--world", type=int, default=1, help="trace rank's share of the tiles (tile t -> rank t mod world)")
     a = ap.parse_args()
-    import bench
-    from volumerendering_amd import capi, host, synth
-    n, W, H, vname = bench.WORKLOADS[a.workload]
+    from volumerendering_amd import capi, host, workloads as wl
+    n, W, H, vname = wl.WORKLOADS[a.workload]
     app = host.Application(W, H, 0)
-    variant, vols = bench.build_scene(app, host, synth, capi, a.workload, a.tf)
+    variant, vols = wl.build_scene(app, a.workload, a.tf)
     ctx = app.context()
     ctx.set_kernel_flavour(a.flavour)
     for _ in range(3):

@@ -2,7 +2,7 @@
 """Experiment: which pairs of streams really overlap two frames (HIP maps streams onto a few hardware queues)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 torch.cuda.init()
 from volumerendering_amd import capi, host, workloads as wl

@@ -4,7 +4,7 @@ the frame (tile t owned by rank t mod N), without the gather, for several kernel
   * kernel ms of the slowest rank, one launch at a time (HIP events), and
   * ms per frame with two launches in flight on two streams, as bench.py drives them (wall clock, rank 0's share).
 
-    python tools_exp_tiles.py [--workload C3] [--tf default] [--flavours 0,6]"""
+    python tools/exp_tiles.py [--workload C3] [--tf default] [--flavours 0,6]"""
 import argparse
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 

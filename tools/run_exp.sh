@@ -1,4 +1,4 @@
-# usage: tools_run_exp.sh <outdir> ; runs a list of bench experiments given on stdin: "<tag> | <env assignments> | <bench args>"
+# usage: tools/run_exp.sh <outdir> ; runs a list of bench experiments given on stdin: "<tag> | <env assignments> | <bench args>"
 OUT=gpurun_out/$1; mkdir -p $OUT
 while IFS='|' read -r TAG ENVS ARGS; do
   TAG=$(echo $TAG); [ -z "$TAG" ] && continue

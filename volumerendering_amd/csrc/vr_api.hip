@@ -323,7 +323,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // is throughput-bound and one lane per ray does the least work; with few (a small frame, or one GPU's share
         // of the tiles) the frame waits for its longest rays, whose chains of dependent steps the depth-parallel
         // kernel cuts to a half or a quarter (vr_dp.h).  Thresholds measured on C3 at 1 / 2 / 4 / 8 ranks (two launches in
-        // flight, tools_exp_tiles.py).
+        // flight, tools/exp_tiles.py).
         const long long px = (long long)tile_count(c, rank, world) * kTile * kTile;
         const double rays_per_lane = (double)px / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
         fl = rays_per_lane >= 4.5 ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);

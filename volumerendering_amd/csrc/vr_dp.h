@@ -7,7 +7,7 @@
 // same positions (each lane runs the ray's chain of rounded additions itself, four additions per round), the same
 // arithmetic, the same blend order, the same sample counts -- but a ray's chain of dependent work is a quarter as long and
 // a wavefront is 16 rays (a 4x4 pixel packet) instead of 64.  That is what the frame time hangs on: with one lane per
-// ray the frame waits for the wavefronts with the longest rays (per-workgroup trace, tools_block_trace.py: longest
+// ray the frame waits for the wavefronts with the longest rays (per-workgroup trace, tools/block_trace.py: longest
 // workgroup 0.9 ms of a 0.93 ms frame while the average busy workgroup takes 0.42 ms), and a GPU that owns an eighth of
 // the tiles is hardly faster than one that owns all of them.  Loop overhead (look-ahead, run test, box test) is also
 // paid once per round of four steps instead of once per step.
