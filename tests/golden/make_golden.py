@@ -33,6 +33,9 @@ def cases():
     # the illustrative shader, rays kept shorter than 1 in texture space (beyond that its pow(0, 0) puts NaNs -- whose
     # payload bits are platform specific -- into the frame; tests/test_parity_gpu.py covers those NaN-aware)
     out.append(("illustrative", 6, dict(base, steps_count=12, yaw=0.9), False))
+    # the lit shader with its own ComputeGradient (BasicVolLightApp.wgsl:212 enabled), fixed and variable step
+    out.append(("inshader", 7, dict(base), False))
+    out.append(("inshader_varstep_thin", 7, dict(base, toggles=(1, 0, 0, 0), yaw=2.1, pitch=-0.4), True))
     return out
 
 
