@@ -425,7 +425,8 @@ def main():
     vol_bytes = sum(int(np.prod(v.GetSize())) * 16 for v in vols)
 
     if mg is not None:
-        gpu_frames = [mg.download(w, W, H) for w in (0, 1)] if rank == 0 else []
+        n_slots = max(1, min(4, int(os.environ.get("VR_MGPU_SLOTS", "2"))))
+        gpu_frames = [mg.download(w, W, H) for w in range(min(2, n_slots))] if rank == 0 else []
     else:
         gpu_frames = [f.cpu().numpy() for f in frames[:2]] if rank == 0 else []
     gpu_frame = gpu_frames[0] if gpu_frames else None
@@ -598,7 +599,7 @@ def main():
         parity["arithmetic"] = args.arith
         out["parity"] = parity
         out["cpu_baseline"] = base
-    if rank == 0 and multi:
+    if rank == 0 and multi and not os.environ.get("VR_MGPU_EXP_SHARE"):
         # the gathered frames must equal a single-rank render of the same scene, bit for bit (cheap: one more frame)
         ctx.render_async(variant, 0, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()

@@ -20,9 +20,11 @@
  *                         issues the per-device calls of a frame inside one ncclGroupStart / ncclGroupEnd.  Scene
  *                         resources are uploaded to every context (vr_mgpu_context(m, i)).
  *
- * Frames are pipelined two deep: frame k+1 renders while frame k's tiles travel and are un-permuted (two tile /
- * gather / frame buffer sets, used alternately).  vr_mgpu_frame_async never blocks the host on the GPU except to
- * bound the pipeline at two frames; vr_mgpu_wait drains it.
+ * Frames are pipelined: frame k+1 renders while frame k's tiles travel and are un-permuted (tile / gather / frame
+ * buffer sets used in turn; two by default, 1..4 with VR_MGPU_SLOTS -- a rank's share of a frame is a short,
+ * latency-bound launch, and more of them in flight raise the frame rate at the price of frames of delay).
+ * vr_mgpu_frame_async never blocks the host on the GPU beyond the C ABI's own bound of four launches in flight;
+ * vr_mgpu_wait drains the pipeline.
  *
  * Conventions as in vr.h: plain C, 0 = ok, negative = vr_status, message via vr_mgpu_last_error; no exception
  * crosses the boundary; one thread at a time per handle.

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -16,7 +17,7 @@
 namespace {
 
 constexpr int kTilePx = 64;
-constexpr int kSlots = 2;  // frames in flight
+constexpr int kSlots = 4;  // buffer sets; vr_mgpu::slots of them are used (frames in flight, default 2, VR_MGPU_SLOTS)
 
 thread_local std::string g_create_error;
 
@@ -42,6 +43,9 @@ struct vr_mgpu {
     uint32_t W = 0, H = 0;
     size_t seg_floats = 0;  // floats per rank segment = max tiles per rank * 64 * 64 * 4
     std::vector<Rank> r;    // the ranks this process drives
+    int slots = 2;          // frames in flight (buffer sets in use)
+    int exp_share = 1;      // experiment (VR_MGPU_EXP_SHARE=N, world of one only): render and gather only rank 0's share of an
+                            // N-rank partition -- the timeline of one rank of an N-GPU run on a one-GPU box; frames are incomplete
     unsigned long long frame_no = 0;
     std::string err, backend;
 };
@@ -79,7 +83,8 @@ int fail(vr_mgpu* m, int code, const std::string& msg)
 int setup_rank(vr_mgpu* m, Rank& k)
 {
     MG_HIP(m, hipSetDevice(k.device));
-    for (int b = 0; b < kSlots; ++b) {
+    const int gather_world = m->exp_share > 1 ? m->exp_share : m->world;
+    for (int b = 0; b < m->slots; ++b) {
         // the context's own streams: probed to really run side by side (two arbitrary streams may share a hardware queue)
         k.s_render[b] = (hipStream_t)vr_stream(k.ctx, b);
         if (!k.s_render[b]) return fail(m, VR_ERR_HIP, "vr_stream: no render stream available");
@@ -88,7 +93,8 @@ int setup_rank(vr_mgpu* m, Rank& k)
         MG_HIP(m, hipMalloc(&k.tiles[b], (m->seg_floats ? m->seg_floats : 4) * sizeof(float)));
         MG_HIP(m, hipMemset(k.tiles[b], 0, (m->seg_floats ? m->seg_floats : 4) * sizeof(float)));
         if (k.rank == 0) {
-            MG_HIP(m, hipMalloc(&k.gathered[b], (m->seg_floats ? m->seg_floats : 4) * (size_t)m->world * sizeof(float)));
+            MG_HIP(m, hipMalloc(&k.gathered[b], (m->seg_floats ? m->seg_floats : 4) * (size_t)gather_world * sizeof(float)));
+            MG_HIP(m, hipMemset(k.gathered[b], 0, (m->seg_floats ? m->seg_floats : 4) * (size_t)gather_world * sizeof(float)));
             MG_HIP(m, hipMalloc(&k.frame[b], (size_t)m->W * m->H * 4 * sizeof(float)));
             MG_HIP(m, hipMemset(k.frame[b], 0, (size_t)m->W * m->H * 4 * sizeof(float)));
         }
@@ -103,12 +109,25 @@ int setup_rank(vr_mgpu* m, Rank& k)
     return VR_OK;
 }
 
+void read_knobs(vr_mgpu* m)
+{
+    if (const char* e = getenv("VR_MGPU_SLOTS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= kSlots) m->slots = v;
+    }
+    if (const char* e = getenv("VR_MGPU_EXP_SHARE")) {
+        const int v = atoi(e);
+        if (v > 1 && m->world == 1) m->exp_share = v;
+    }
+}
+
 void describe_backend(vr_mgpu* m)
 {
     int v = 0;
     (void)ncclGetVersion(&v);
     m->backend = "RCCL " + std::to_string(v / 10000) + "." + std::to_string((v / 100) % 100) + "." + std::to_string(v % 100) +
-                 " ncclGather over xGMI, root = rank 0";
+                 " ncclGather over xGMI, root = rank 0, " + std::to_string(m->slots) + " frames in flight" +
+                 (m->exp_share > 1 ? " [EXPERIMENT: one rank's share of " + std::to_string(m->exp_share) + "]" : "");
 }
 
 }  // namespace
@@ -141,9 +160,10 @@ int vr_mgpu_create(vr_mgpu** out, vr_ctx* ctx, int rank, int world, const void* 
         return code;
     };
     m->world = world;
+    read_knobs(m);
     int dev = 0;
     if (vr_viewport(ctx, &m->W, &m->H, &dev) != VR_OK) return bail(fail(m, VR_ERR_INVALID_ARG, "vr_mgpu_create: bad context"));
-    m->seg_floats = (size_t)vr_tile_count(ctx, 0, world) * kTilePx * kTilePx * 4;
+    m->seg_floats = (size_t)vr_tile_count(ctx, 0, m->exp_share > 1 ? m->exp_share : world) * kTilePx * kTilePx * 4;
     m->r.resize(1);
     Rank& k = m->r[0];
     k.device = dev;
@@ -173,6 +193,8 @@ int vr_mgpu_create_local(vr_mgpu** out, uint32_t width, uint32_t height, const i
         return code;
     };
     m->world = n_devices;
+    read_knobs(m);
+    m->exp_share = 1;
     m->W = width;
     m->H = height;
     m->r.resize((size_t)n_devices);
@@ -234,12 +256,13 @@ const char* vr_mgpu_backend(const vr_mgpu* m) { return m ? m->backend.c_str() : 
 int vr_mgpu_frame_async(vr_mgpu* m, int variant)
 {
     if (!m) return VR_ERR_INVALID_ARG;
-    const int b = (int)(m->frame_no % kSlots);
+    const int b = (int)(m->frame_no % (unsigned long long)m->slots);
+    const int part_world = m->exp_share > 1 ? m->exp_share : m->world;
     // 1. every local rank renders its tiles into buffer set b (behind the gather that last read that buffer)
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
         if (k.used[b]) MG_HIP(m, hipStreamWaitEvent(k.s_render[b], k.ev_done[b], 0));
-        MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, m->world, k.tiles[b], k.s_render[b]));
+        MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, part_world, k.tiles[b], k.s_render[b]));
         MG_HIP(m, hipEventRecord(k.ev_render[b], k.s_render[b]));
         MG_HIP(m, hipStreamWaitEvent(k.s_comm, k.ev_render[b], 0));
     }
@@ -255,7 +278,7 @@ int vr_mgpu_frame_async(vr_mgpu* m, int variant)
     // 3. the root scatters the segments into the frame; the buffer set is free again when that is done
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
-        if (k.rank == 0) MG_VR(m, k, vr_unpack_tiles_async(k.ctx, k.gathered[b], m->world, k.frame[b], k.s_comm));
+        if (k.rank == 0) MG_VR(m, k, vr_unpack_tiles_async(k.ctx, k.gathered[b], part_world, k.frame[b], k.s_comm));
         MG_HIP(m, hipEventRecord(k.ev_done[b], k.s_comm));
         k.used[b] = true;
     }
@@ -268,7 +291,7 @@ int vr_mgpu_wait(vr_mgpu* m)
     if (!m) return VR_ERR_INVALID_ARG;
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
-        for (int b = 0; b < kSlots; ++b) MG_HIP(m, hipStreamSynchronize(k.s_render[b]));
+        for (int b = 0; b < m->slots; ++b) MG_HIP(m, hipStreamSynchronize(k.s_render[b]));
         MG_HIP(m, hipStreamSynchronize(k.s_comm));
     }
     return VR_OK;
@@ -276,7 +299,7 @@ int vr_mgpu_wait(vr_mgpu* m)
 
 void* vr_mgpu_frame_device_ptr(vr_mgpu* m, int which)
 {
-    if (!m || which < 0 || which >= kSlots) return nullptr;
+    if (!m || which < 0 || which >= m->slots) return nullptr;
     for (auto& k : m->r)
         if (k.rank == 0) return k.frame[which];
     return nullptr;
@@ -284,7 +307,7 @@ void* vr_mgpu_frame_device_ptr(vr_mgpu* m, int which)
 
 int vr_mgpu_download(vr_mgpu* m, int which, float* frag_rgba)
 {
-    if (!m || !frag_rgba || which < 0 || which >= kSlots) return VR_ERR_INVALID_ARG;
+    if (!m || !frag_rgba || which < 0 || which >= m->slots) return VR_ERR_INVALID_ARG;
     int rc = vr_mgpu_wait(m);
     if (rc != VR_OK) return rc;
     for (auto& k : m->r)
