@@ -29,7 +29,7 @@ def main():
     variant, vols = wl.build_scene(app, a.workload, a.tf)
     ctx = app.context()
     ctx.set_kernel_flavour(a.flavour)
-    for _ in range(3):
+    for _ in range(6):   # the launch order is three launches old: let it settle
         if a.world > 1:
             ctx.render_tiles(variant, a.rank, a.world)
         else:
@@ -56,9 +56,13 @@ def main():
               f"busy {dur[m].sum():9.0f} us  fetched {tr[m, 2].sum():10d}  composited {tr[m, 0].sum():11d}  CUs seen {len(set(zip(se[m].tolist(), cu[m].tolist())))}")
     order = np.argsort(-dur)[:12]
     print("longest workgroups: duration us / start us / fetched / composited / XCD / tile ordinal")
-    for i in order:
-        tile = (i & 7) + 8 * ((i >> 3) // 16)
-        print(f"   {dur[i]:7.1f} {(t0[i] - base) / 100.0:7.1f} {tr[i, 2]:8d} {tr[i, 0]:8d}   {xcc[i]}  {tile}  chain {crit[i]}")
+    per_tile = len(tr) // max(1, ctx.tile_count(a.rank, a.world) if a.world > 1 else ((W + 63) // 64) * ((H + 63) // 64))
+    for i in order:   # records are indexed by LOGICAL block: consecutive blocks of a tile
+        print(f"   {dur[i]:7.1f} {(t0[i] - base) / 100.0:7.1f} {tr[i, 2]:8d} {tr[i, 0]:8d}   {xcc[i]}  {i // max(1, per_tile)}  chain {crit[i]}")
+    # how well does the start order follow the chain lengths?  (longest-first launch order)
+    rank_start = np.argsort(np.argsort(t0))
+    rank_chain = np.argsort(np.argsort(-crit))
+    print(f"rank correlation of start time with descending chain length: {np.corrcoef(rank_start, rank_chain)[0, 1]:.3f}")
     print(f"longest sample chain {crit.max()}  p99 {np.percentile(crit[heavy], 99):.0f}  median of busy workgroups {np.median(crit[heavy]):.0f}")
     # residency over time (20 bins)
     edges = np.linspace(0, span, 21)

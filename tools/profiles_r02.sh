@@ -21,6 +21,7 @@ $B --air noisy --layout 1 > $OUT/c3_noisy_vec4.json 2> $OUT/c3_noisy_vec4.err; e
 $B --air noisy --layout 2 > $OUT/c3_noisy_otf.json 2> $OUT/c3_noisy_otf.err; echo "c3 noisy otf rc $?"
 $B --layout 2 > $OUT/c3_otf.json 2> $OUT/c3_otf.err; echo "c3 otf rc $?"
 $B --tf thin > $OUT/c3_thin.json 2> $OUT/c3_thin.err; echo "c3 thin rc $?"
+$B --flavour 1 > $OUT/c3_flavour1.json 2> $OUT/c3_flavour1.err; echo "c3 flavour1 rc $?"
 $B --air noisy --flavour 2 > $OUT/c3_noisy_wtb.json 2> $OUT/c3_noisy_wtb.err; echo "c3 noisy wtb rc $?"
 VR_EXP_WAVES_PER_BLOCK=4 $B > $OUT/c3_wpb4.json 2> $OUT/c3_wpb4.err; echo "c3 wpb4 rc $?"
 VR_EXP_ORDER=0 $B > $OUT/c3_noorder.json 2> $OUT/c3_noorder.err; echo "c3 noorder rc $?"
