@@ -86,8 +86,11 @@ struct vr_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t sorted = nullptr;
         unsigned long long key = 0, seq = 0;
+        unsigned long long scene_key = 0;  // what the launch rendered, whatever kernel form it took (the chain length's key)
         bool valid = false;
     } order_ring[kOrderRing];
+    unsigned* h_chain = nullptr;  // pinned, one word per ring slot: longest ray chain + 1 of that launch (0 = not known yet)
+    hipStream_t slot_stream[kInFlight] = {};  // the stream each of the last kInFlight launches went to
     unsigned long long order_seq = 0;
     hipStream_t flight[kInFlight] = {};  // vr_stream(): streams probed to run side by side (created on first use)
     int n_flight = 0;
@@ -319,14 +322,44 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     const int sv = (variant == VR_VARIANT_VOLUME_MASK) ? 2 : 0;  // the volume whose density drives tf[0]'s opacity
     int fl = c->flavour == 0 ? c->default_flavour : c->flavour;
     if (fl == 0) {
-        // Default: pick the lanes per ray from the size of the launch.  With many rays per hardware lane the machine
-        // is throughput-bound and one lane per ray does the least work; with few (a small frame, or one GPU's share
-        // of the tiles) the frame waits for its longest rays, whose chains of dependent steps the depth-parallel
-        // kernel cuts to a half or a quarter (vr_dp.h).  Thresholds measured on C3 at 1 / 2 / 4 / 8 ranks (two launches in
-        // flight, tools/exp_tiles.py).
+        // Default: pick the lanes per ray from what will be on the machine.  With many rays per hardware lane the machine is
+        // throughput-bound and one lane per ray does the least work; with few (a small frame, or one GPU's share of the
+        // tiles) the frame waits for its longest rays, whose chains of dependent samples the depth-parallel kernel cuts to a
+        // half or a quarter (vr_dp.h).  Two things refine the round-1 rule (thresholds measured on C3 at 1 / 2 / 4 / 8 ranks):
+        //  * frames in flight: launches still running on OTHER streams fill the machine as well, so the rays per lane count
+        //    once per stream in flight (a rank's half of C3, two frames pipelined: 0.34 ms with one lane, 0.42 with two);
+        //  * how long the chains really are: the longest ray chain of an earlier launch of this shape (written to pinned
+        //    memory by the launch-order sort; read here without synchronising, 0 = not known).  Chains too short to matter --
+        //    under 75 samples, 0.12 ms -- leave nothing for the depth-parallel kernels to cut (C2: 0.133 / 0.091 ms per frame
+        //    with one lane, 0.153 / 0.123 with two), unless the launch is too small to fill the machine at all.
         const long long px = (long long)tile_count(c, rank, world) * kTile * kTile;
-        const double rays_per_lane = (double)px / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
-        fl = rays_per_lane >= 4.5 ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
+        int in_flight = 1;
+        {
+            hipStream_t seen[kInFlight + 1] = {s};
+            for (int i = 0; i < kInFlight; ++i) {
+                if (!c->slot_used[i] || hipEventQuery(c->slot_done[i]) != hipErrorNotReady) continue;
+                bool dup = false;
+                for (int k = 0; k < in_flight; ++k) dup = dup || seen[k] == c->slot_stream[i];
+                if (!dup) seen[in_flight++] = c->slot_stream[i];
+            }
+            (void)hipGetLastError();  // hipErrorNotReady is not an error
+        }
+        const double rays_per_lane = (double)px * in_flight / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
+        unsigned chain = 0;  // longest chain + 1 of the most recent launch of this scene shape whose sort has reported
+        if (c->h_chain) {
+            const unsigned long long skey = ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
+                                            (packed ? 1ull << 63 : 0ull) ^ ((unsigned long long)c->W << 40) ^ ((unsigned long long)c->H << 24);
+            unsigned long long best_seq = 0;
+            for (int i = 0; i < kOrderRing; ++i) {
+                const unsigned v = *(volatile unsigned*)&c->h_chain[i];
+                if (v != 0 && c->order_ring[i].scene_key == skey && c->order_ring[i].seq + 1 > best_seq) {
+                    best_seq = c->order_ring[i].seq + 1;
+                    chain = v;
+                }
+            }
+        }
+        const bool short_chains = chain != 0 && chain - 1 < 75;
+        fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
     }
     // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
     if (variant == VR_VARIANT_ILLUSTRATIVE && (fl == 7 || fl == 8 || fl == 10 || fl == 11)) fl = 6;
@@ -451,6 +484,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         P.block_counts = c->d_block_counts[cb];
         c->cnt_buf = cb;
+        c->slot_stream[cb] = s;
         // launch order: the most recent sort of a launch of the same shape that is three or four launches old -- a younger
         // one may still be waiting for its launch to finish (the sorts run on a side stream behind their launches; waiting
         // for one would put a bubble into this stream), an older one's buffer may be recycled under this launch; ordered
@@ -501,14 +535,18 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             }
             o.stream = s;
             o.key = okey;
+            o.scene_key = ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
+                          (packed ? 1ull << 63 : 0ull) ^ ((unsigned long long)c->W << 40) ^ ((unsigned long long)c->H << 24);
             o.seq = c->order_seq;
+            if (c->h_chain) c->h_chain[c->order_seq % kOrderRing] = 0;  // not known until this launch's sort has run
         }
         VR_HIP(c, hipEventRecord(c->slot_done[cb], s));
         c->slot_used[cb] = true;
         if (ordered) {
             vr_ctx::OrderSlot& o = c->order_ring[c->order_seq % kOrderRing];
             VR_HIP(c, hipStreamWaitEvent(c->order_stream, c->slot_done[cb], 0));
-            hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, c->order_stream, c->d_block_counts[cb], (int)grid.x, o.buf);
+            hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, c->order_stream, c->d_block_counts[cb], (int)grid.x, o.buf,
+                               c->h_chain ? c->h_chain + (c->order_seq % kOrderRing) : (unsigned*)nullptr);
             VR_HIP(c, hipGetLastError());
             VR_HIP(c, hipEventRecord(o.sorted, c->order_stream));
             o.valid = true;
@@ -771,6 +809,10 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     for (auto& o : c->order_ring)
         if (!hip_ok(hipEventCreateWithFlags(&o.sorted, hipEventDisableTiming), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipStreamCreateWithFlags(&c->order_stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(VR_ERR_HIP);
+    if (hipHostMalloc((void**)&c->h_chain, kOrderRing * sizeof(unsigned), hipHostMallocDefault) == hipSuccess)
+        std::memset(c->h_chain, 0, kOrderRing * sizeof(unsigned));
+    else
+        c->h_chain = nullptr;  // (the choice of lanes per ray then goes by the launch size alone)
     if (const char* e = getenv("VR_EXP_ORDER")) c->order_mode = atoi(e);
     if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 3 * sizeof(unsigned long long), hipHostMallocDefault),
@@ -830,6 +872,7 @@ void vr_destroy(vr_ctx* c)
         if (o.buf) (void)hipFree(o.buf);
     }
     if (c->order_stream) (void)hipStreamDestroy(c->order_stream);
+    if (c->h_chain) (void)hipHostFree(c->h_chain);
     for (int k = 0; k < c->n_flight; ++k) (void)hipStreamDestroy(c->flight[k]);
     if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
     if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);

@@ -1430,12 +1430,15 @@ __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks, unsi
 // blocks longest-processing-time-first.  Eight counting sorts over 128 key buckets each (n_blocks % 8 == 0).
 constexpr int kOrderMaxBlocks = 192 * 1024;  // launches with more blocks keep the index order (C5, one wavefront per block: 130 560)
 __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long long* __restrict__ in, int n_blocks,
-                                                            unsigned* __restrict__ order)
+                                                            unsigned* __restrict__ order, unsigned* __restrict__ longest_chain)
 {
     __shared__ unsigned hist[1024];  // [class 0..7][bucket 0..127]
     __shared__ unsigned base[1024];
+    __shared__ unsigned chain_max;
     const int t = threadIdx.x;
     hist[t] = 0;
+    if (t == 0) chain_max = 0;
+    unsigned my_chain = 0;
     __syncthreads();
     // every record is read ONCE (a launch that recycles the record buffer under this kernel can then only change the
     // order, never make it something other than a permutation); bucket 0 = the longest chains (32 steps per bucket)
@@ -1444,6 +1447,7 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
         const int b = t + k * 1024;
         if (b < n_blocks) {
             const unsigned long long crit = in[(size_t)b * kBlockRecord + 5] >> 40;
+            my_chain = crit > my_chain ? (unsigned)crit : my_chain;
             const unsigned q = (unsigned)(crit >> 5);
             bk[k] = (unsigned short)(((unsigned)b & 7u) * 128u + (127u - (q > 127u ? 127u : q)));
             atomicAdd(&hist[bk[k]], 1u);
@@ -1465,6 +1469,13 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
         base[t] = before + incl - mine;
     }
     __syncthreads();
+    // the launch's longest ray chain + 1 (0 = not written yet), to host-visible memory: the host's choice of lanes per ray for
+    // a later launch of the same shape reads it without synchronising (vr_api.hip, enqueue_render)
+    if (longest_chain) {
+        atomicMax(&chain_max, my_chain);
+        __syncthreads();
+        if (t == 0) *longest_chain = chain_max + 1u;
+    }
     // scatter with one cursor per (class, bucket): the i-th block of class x goes to position 8 * i + x
     for (int k = 0; k * 1024 < n_blocks; ++k) {
         const int b = t + k * 1024;
