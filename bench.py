@@ -355,6 +355,7 @@ def main():
     def timed_leg(nbuf, n_warm, n_steps, min_events=0):
         """W warm-up + exactly K timed frames, barrier + synchronise on both sides; the MAX over ranks of the wall time.
         Returns (seconds, HIP-event kernel durations of the timed launches [+ extra serial frames up to min_events])."""
+        ctx.hint_frames_in_flight(nbuf)  # what this leg's caller does: steers the default kernel choice (vr.h)
         run_frames(n_warm, nbuf)
         sync_all()
         ctx.reset_kernel_times()
@@ -395,7 +396,9 @@ def main():
                 "value": round(total_samples / (dt / args.steps) / 1e9, 3),
                 "fetched_gsamples_per_s": round(total_fetched / (dt / args.steps) / 1e9, 3),
                 "kernel_ms_median": round(float(np.median(kt)), 4) if len(kt) else None,
-                "kernel_ms_mean": round(float(np.mean(kt)), 4) if len(kt) else None, "kernel_events": int(len(kt))}
+                "kernel_ms_mean": round(float(np.mean(kt)), 4) if len(kt) else None,
+                "kernel_ms_p10_p90": [round(float(np.percentile(kt, 10)), 4), round(float(np.percentile(kt, 90)), 4)] if len(kt) else None,
+                "kernel_events": int(len(kt))}
 
     serial, over = leg(dt_serial, kt_serial, 1), leg(dt_over, kt_over, nbuf_over)
     # the other arithmetic mode, same scene, both legs (20 frames each; outside the K-step regions above)
@@ -574,6 +577,7 @@ def main():
             current = (air, tf)
 
         regimes = []
+        ctx.hint_frames_in_flight(1)
         for air in wl.AIR_KINDS:
             for tf in ("default", "prefix"):
                 scene(air, tf)

@@ -198,6 +198,12 @@ int vr_render_async(vr_ctx* ctx, int variant, void* d_frame, void* stream);
  * to really run side by side (two 150 us single-wavefront kernels; ~3 ms once); fewer than four may exist, then the index
  * wraps.  Use them in turn for vr_render_async / vr_render_tiles_async; NULL on failure.                              */
 void* vr_stream(vr_ctx* ctx, int index);
+
+/* Hint: how many frames the caller keeps in flight on different streams (1 = one at a time, the default; up to 4).  It only
+ * steers the default choice of lanes per ray (vr_set_kernel_flavour(0)): frames that overlap fill the machine together, so
+ * the throughput-optimal one-lane kernel is preferred earlier than for a frame that has the machine to itself.  Results do
+ * not depend on it.                                                                                                    */
+int vr_hint_frames_in_flight(vr_ctx* ctx, int frames);
 int vr_render_tiles_async(vr_ctx* ctx, int variant, int rank, int world, void* d_tiles, void* stream);
 
 /* Root side of the gather: `d_gathered` holds, for r = 0..world-1, rank r's packed tiles, each

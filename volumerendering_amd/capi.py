@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
-    "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream",
+    "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream", "vr_hint_frames_in_flight",
 ]
 
 
@@ -109,6 +109,7 @@ def load() -> C.CDLL:
     lib.vr_set_volume_layout.argtypes = [vp, i32]
     lib.vr_set_arithmetic.argtypes = [vp, i32]
     lib.vr_present_async.argtypes = [vp, vp, vp, vp]
+    lib.vr_hint_frames_in_flight.argtypes = [vp, i32]
     lib.vr_stream.argtypes = [vp, i32]
     lib.vr_stream.restype = vp
     lib.vr_volume_layout.argtypes = [vp, i32, C.POINTER(C.c_int)]
@@ -278,6 +279,10 @@ class Context:
 
     def last_kernel_flavour(self) -> int:
         return self._chk(self.lib.vr_last_kernel_flavour(self.h))
+
+    def hint_frames_in_flight(self, frames: int):
+        """How many frames the caller keeps in flight on different streams (steers the default kernel choice only)."""
+        self._chk(self.lib.vr_hint_frames_in_flight(self.h, frames))
 
     def stream(self, index: int) -> int:
         """Context-owned stream `index` (0..3) of a set probed to run side by side: use them in turn for frames in flight."""

@@ -90,7 +90,7 @@ struct vr_ctx {
         bool valid = false;
     } order_ring[kOrderRing];
     unsigned* h_chain = nullptr;  // pinned, one word per ring slot: longest ray chain + 1 of that launch (0 = not known yet)
-    hipStream_t slot_stream[kInFlight] = {};  // the stream each of the last kInFlight launches went to
+    int frames_in_flight = 1;                 // vr_hint_frames_in_flight: frames the caller keeps in flight on different streams
     unsigned long long order_seq = 0;
     hipStream_t flight[kInFlight] = {};  // vr_stream(): streams probed to run side by side (created on first use)
     int n_flight = 0;
@@ -326,24 +326,16 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // throughput-bound and one lane per ray does the least work; with few (a small frame, or one GPU's share of the
         // tiles) the frame waits for its longest rays, whose chains of dependent samples the depth-parallel kernel cuts to a
         // half or a quarter (vr_dp.h).  Two things refine the round-1 rule (thresholds measured on C3 at 1 / 2 / 4 / 8 ranks):
-        //  * frames in flight: launches still running on OTHER streams fill the machine as well, so the rays per lane count
-        //    once per stream in flight (a rank's half of C3, two frames pipelined: 0.34 ms with one lane, 0.42 with two);
+        //  * frames in flight: when the caller keeps several frames in flight on different streams (it says so with
+        //    vr_hint_frames_in_flight; asking the events instead flushes the runtime's command batches and costs more than it
+        //    tells) the other launches fill the machine as well, so the rays per lane count once per frame in flight (a
+        //    rank's half of C3, two frames pipelined: 0.34 ms with one lane, 0.42 with two);
         //  * how long the chains really are: the longest ray chain of an earlier launch of this shape (written to pinned
         //    memory by the launch-order sort; read here without synchronising, 0 = not known).  Chains too short to matter --
         //    under 75 samples, 0.12 ms -- leave nothing for the depth-parallel kernels to cut (C2: 0.133 / 0.091 ms per frame
         //    with one lane, 0.153 / 0.123 with two), unless the launch is too small to fill the machine at all.
         const long long px = (long long)tile_count(c, rank, world) * kTile * kTile;
-        int in_flight = 1;
-        {
-            hipStream_t seen[kInFlight + 1] = {s};
-            for (int i = 0; i < kInFlight; ++i) {
-                if (!c->slot_used[i] || hipEventQuery(c->slot_done[i]) != hipErrorNotReady) continue;
-                bool dup = false;
-                for (int k = 0; k < in_flight; ++k) dup = dup || seen[k] == c->slot_stream[i];
-                if (!dup) seen[in_flight++] = c->slot_stream[i];
-            }
-            (void)hipGetLastError();  // hipErrorNotReady is not an error
-        }
+        const int in_flight = c->frames_in_flight;  // the caller's hint (vr_hint_frames_in_flight)
         const double rays_per_lane = (double)px * in_flight / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
         unsigned chain = 0;  // longest chain + 1 of the most recent launch of this scene shape whose sort has reported
         if (c->h_chain) {
@@ -484,7 +476,6 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         P.block_counts = c->d_block_counts[cb];
         c->cnt_buf = cb;
-        c->slot_stream[cb] = s;
         // launch order: the most recent sort of a launch of the same shape that is three or four launches old -- a younger
         // one may still be waiting for its launch to finish (the sorts run on a side stream behind their launches; waiting
         // for one would put a bubble into this stream), an older one's buffer may be recycled under this launch; ordered
@@ -1234,6 +1225,14 @@ void* vr_stream(vr_ctx* c, int index)
         if (c->n_flight == 0) return nullptr;
     }
     return (void*)c->flight[index % c->n_flight];
+}
+
+int vr_hint_frames_in_flight(vr_ctx* c, int frames)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (frames < 1 || frames > kInFlight) return fail(c, VR_ERR_INVALID_ARG, "vr_hint_frames_in_flight: 1 .. 4");
+    c->frames_in_flight = frames;
+    return VR_OK;
 }
 
 int vr_set_arithmetic(vr_ctx* c, int mode)
