@@ -24,7 +24,9 @@
  * buffer sets used in turn; two by default, 1..4 with VR_MGPU_SLOTS -- a rank's share of a frame is a short,
  * latency-bound launch, and more of them in flight raise the frame rate at the price of frames of delay).
  * vr_mgpu_frame_async never blocks the host on the GPU beyond the C ABI's own bound of four launches in flight;
- * vr_mgpu_wait drains the pipeline.
+ * vr_mgpu_wait drains the pipeline.  A caller that really keeps frames in flight says so on every rank's context
+ * (vr_hint_frames_in_flight(ctx, 2)): a rank's share is a small launch, and the default choice of lanes per ray depends
+ * on whether other frames fill the machine beside it.
  *
  * Conventions as in vr.h: plain C, 0 = ok, negative = vr_status, message via vr_mgpu_last_error; no exception
  * crosses the boundary; one thread at a time per handle.
