@@ -332,7 +332,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         //    rank's half of C3, two frames pipelined: 0.34 ms with one lane, 0.42 with two);
         //  * how long the chains really are: the longest ray chain of an earlier launch of this shape (written to pinned
         //    memory by the launch-order sort; read here without synchronising, 0 = not known).  Chains too short to matter --
-        //    under 75 samples, 0.12 ms -- leave nothing for the depth-parallel kernels to cut (C2: 0.133 / 0.091 ms per frame
+        //    under 128 samples, 0.2 ms (C2: 102) -- leave nothing for the depth-parallel kernels to cut (C2: 0.133 / 0.091 ms per frame
         //    with one lane, 0.153 / 0.123 with two), unless the launch is too small to fill the machine at all.
         const long long px = (long long)tile_count(c, rank, world) * kTile * kTile;
         const int in_flight = c->frames_in_flight;  // the caller's hint (vr_hint_frames_in_flight)
@@ -350,7 +350,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 }
             }
         }
-        const bool short_chains = chain != 0 && chain - 1 < 75;
+        const bool short_chains = chain != 0 && chain - 1 < 128;
         fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
     }
     // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
