@@ -201,9 +201,12 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
                         if (__ballot(m < 32) == 0) mw = __ballot(m < 64) == 0 ? 64 : 32;
                     }
                 }
-                for (int k = 0; k < mw; ++k) {
-                    p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
-                    if constexpr (kW) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                for (int k = 0; k < mw; k += 4) {  // mw is a multiple of 4: one branch per four steps
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                        if constexpr (kW) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                    }
                 }
                 base += mw;
                 blends += alive ? (unsigned)mw : 0u;

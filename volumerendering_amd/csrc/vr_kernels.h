@@ -1168,10 +1168,13 @@ __global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kern
                                     if (__ballot(m < 32) == 0) mw = __ballot(m < 64) == 0 ? 64 : 32;
                                 }
                             }
-                            for (int k = 0; k < mw; ++k) {
-                                p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
-                                if constexpr (V != V_BASIC && V != V_TF_CALIB)
-                                    w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                            for (int k = 0; k < mw; k += 4) {  // mw is a multiple of 4: one branch per four steps
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                                    if constexpr (V != V_BASIC && V != V_TF_CALIB)
+                                        w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                                }
                             }
                             i += mw;
                             blends += (unsigned)mw;
