@@ -1,0 +1,139 @@
+"""The multi-rank logic of the C++ frame loop (csrc/mgpu/vr_mgpu.cpp) with a world of 2..8 ranks ON ONE GPU.
+
+RCCL refuses two ranks on one device, so the shipped libvr_mgpu.so can only be run here with a world of one
+(tests/test_mgpu_gpu.py: that covers the RCCL calls themselves).  What a world of one cannot reach -- segment offsets in
+the gather buffer, ranks that own fewer tiles than rank 0 (or none), the interleaved un-permute over several segments, the
+buffer sets of pipelined frames with several ranks, the counter reduction -- is exercised here by linking THE SAME source
+file against an in-process loopback communicator (tests/loopback_comm/loopback_comm.cpp: gather = stream-ordered
+device-to-device copies, same group semantics) instead of librccl.  Every rank's context lives on device 0.  The assembled
+frame must equal vr_render's bit for bit.  Transport over xGMI with N > 1 stays unmeasured on hardware here (the driver's
+SCALE run is the only multi-GPU run)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import host_ref as hr
+import vrtest as vt
+from volumerendering_amd import build, capi, mgpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(HERE, "_build")
+PKG = os.path.join(ROOT, "volumerendering_amd")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def build_loopback() -> str:
+    os.makedirs(OUT, exist_ok=True)
+    build.build_hip()
+    comm = os.path.join(OUT, "libloopback_comm.so")
+    loop = os.path.join(OUT, "libvr_mgpu_loopback.so")
+    common = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+              "-I", os.path.join(ROCM, "include")]
+    rpaths = ["-Wl,-rpath," + OUT, "-Wl,-rpath," + PKG, "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    subprocess.run(common + ["-o", comm, os.path.join(HERE, "loopback_comm", "loopback_comm.cpp"), "-L", os.path.join(ROCM, "lib"),
+                             "-lamdhip64"] + rpaths, check=True)
+    subprocess.run(common + ["-o", loop, os.path.join(PKG, "csrc", "mgpu", "vr_mgpu.cpp"), "-L", OUT, "-lloopback_comm", "-L", PKG,
+                             "-lvr_hip", "-L", os.path.join(ROCM, "lib"), "-lamdhip64"] + rpaths, check=True)
+    return loop
+
+
+def test_loopback_build_never_touches_rccl():
+    """(CPU) the test double builds, exports the whole vr_mgpu ABI, and is not linked against librccl; the SHIPPED library is."""
+    loop = build_loopback()
+    needed = subprocess.run(["readelf", "-d", loop], capture_output=True, text=True, check=True).stdout
+    assert "libloopback_comm.so" in needed and "librccl" not in needed
+    syms = subprocess.run(["nm", "-D", "--defined-only", loop], capture_output=True, text=True, check=True).stdout
+    for s in mgpu.ABI_SYMBOLS:
+        assert f" T {s}" in syms, s
+    shipped = subprocess.run(["readelf", "-d", build.build_mgpu()], capture_output=True, text=True, check=True).stdout
+    assert "librccl" in shipped and "loopback" not in shipped
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return mgpu.bind(build_loopback())
+
+
+def scene(ctx, W, H, variant, yaw=0.6):
+    vols, tfs = vt.scene(variant, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=yaw)
+    for i, v in enumerate(vols):
+        ctx.volume_upload(i, v)
+    for i, t in enumerate(tfs):
+        ctx.tf_upload(i, t[0], t[1])
+    ctx.set_uniforms(vt.to_capi_uniforms(u))
+    return u
+
+
+def reference(W, H, variant, yaw=0.6):
+    with capi.Context(W, H, 0) as ctx:
+        scene(ctx, W, H, variant, yaw)
+        ctx.render(variant)
+        frame, _, n = ctx.download()
+        return frame, n, ctx.covered_pixels()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+@pytest.mark.parametrize("variant", [capi.LIGHT, capi.VOLUME_MASK])
+def test_n_ranks_assemble_the_single_gpu_frame(lib, world, variant):
+    W, H = 200, 150   # 4 x 3 ragged tiles: with 5 and 8 ranks the ranks own different numbers of tiles
+    ref, n_ref, cov = reference(W, H, variant)
+    with mgpu.MultiGpu.local(W, H, [0] * world, _lib=lib) as m:
+        assert m.world() == world and m.local_ranks() == world and "RCCL 0.0.0" in m.backend()
+        for r in range(world):
+            scene(m.context(r), W, H, variant)
+        slots = [m.frame_async(variant) for _ in range(5)]
+        assert slots == [0, 1, 0, 1, 0]
+        m.wait()
+        for which in (0, 1):
+            assert np.array_equal(vt.bits(m.download(which, W, H)), vt.bits(ref)), which
+        (comp, covered, fetched), mx = m.reduce(1.25)
+        assert comp == n_ref and covered == cov and 0 < fetched <= comp and mx == 1.25
+        # every rank rendered only its own tiles: the ranks' composited samples add up, none of them has them all
+        per_rank = [m.context(r).counters()[0] for r in range(world)]
+        assert sum(per_rank) == n_ref and max(per_rank) < n_ref
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_tiles(lib):
+    W, H = 64, 64   # one tile: ranks 1 and 2 own nothing and still take part in every collective
+    ref, n_ref, cov = reference(W, H, capi.BASIC)
+    with mgpu.MultiGpu.local(W, H, [0, 0, 0], _lib=lib) as m:
+        for r in range(3):
+            scene(m.context(r), W, H, capi.BASIC)
+        for _ in range(3):
+            m.frame_async(capi.BASIC)
+        assert np.array_equal(vt.bits(m.download(0, W, H)), vt.bits(ref))
+        (comp, covered, _), _ = m.reduce()
+        assert comp == n_ref and covered == cov
+        assert [m.context(r).counters()[0] for r in range(3)] == [n_ref, 0, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_slots", [1, 2, 4])
+def test_pipelined_frames_land_in_their_buffer_sets(lib, n_slots, monkeypatch):
+    """A different camera per frame, nothing waited for in between: frame k is found in buffer set k mod slots."""
+    monkeypatch.setenv("VR_MGPU_SLOTS", str(n_slots))
+    W, H, world = 192, 128, 4
+    yaws = [0.1, 0.6, 1.1, 1.6, 2.1, 2.6]
+    refs = [reference(W, H, capi.LIGHT, y)[0] for y in yaws]
+    with mgpu.MultiGpu.local(W, H, [0] * world, _lib=lib) as m:
+        us = None
+        for r in range(world):
+            us = scene(m.context(r), W, H, capi.LIGHT)
+        landed = {}
+        for k, y in enumerate(yaws):
+            step, count = hr.stepping_params(24, 24, 24)
+            u = vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=y))
+            for r in range(world):
+                m.context(r).set_uniforms(u)
+            landed[m.frame_async(capi.LIGHT)] = k
+        assert sorted(landed) == list(range(n_slots))
+        m.wait()
+        for slot, k in landed.items():
+            assert np.array_equal(vt.bits(m.download(slot, W, H)), vt.bits(refs[k])), (slot, k)

@@ -20,14 +20,11 @@ ABI_SYMBOLS = ["vr_mgpu_unique_id", "vr_mgpu_create", "vr_mgpu_create_local", "v
 _lib = None
 
 
-def load() -> C.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+def bind(path: str) -> C.CDLL:
+    """Load a build of csrc/mgpu/vr_mgpu.cpp and declare its prototypes.  load() binds the shipped library; the tests also
+    bind a copy linked against their in-process loopback communicator (tests/loopback_comm)."""
     capi.load()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
     lib.vr_mgpu_unique_id.argtypes = [vp]
     lib.vr_mgpu_create.argtypes = [C.POINTER(vp), vp, i32, i32, vp]
@@ -48,8 +45,16 @@ def load() -> C.CDLL:
     lib.vr_mgpu_reduce.argtypes = [vp, C.POINTER(C.c_uint64 * 3), C.c_double, C.POINTER(C.c_double)]
     lib.vr_mgpu_backend.argtypes = [vp]
     lib.vr_mgpu_backend.restype = C.c_char_p
-    _lib = lib
     return lib
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        _lib = bind(LIB_PATH)
+    return _lib
 
 
 def unique_id() -> bytes:
@@ -63,8 +68,8 @@ def unique_id() -> bytes:
 class MultiGpu:
     """One process per GPU: MultiGpu(ctx_handle, rank, world, id).  One process, N GPUs: MultiGpu.local(W, H, devices)."""
 
-    def __init__(self, ctx_handle=None, rank=0, world=1, id128: bytes = b"", _local=None):
-        self.lib = load()
+    def __init__(self, ctx_handle=None, rank=0, world=1, id128: bytes = b"", _local=None, _lib=None):
+        self.lib = _lib if _lib is not None else load()
         self.h = C.c_void_p()
         if _local is not None:
             W, H, devs = _local
@@ -79,8 +84,8 @@ class MultiGpu:
             raise capi.VrError(rc, (self.lib.vr_mgpu_last_error(None) or b"").decode())
 
     @classmethod
-    def local(cls, W, H, devices):
-        return cls(_local=(W, H, list(devices)))
+    def local(cls, W, H, devices, _lib=None):
+        return cls(_local=(W, H, list(devices)), _lib=_lib)
 
     def _chk(self, rc):
         if rc < 0:
