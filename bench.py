@@ -300,7 +300,9 @@ def main():
 
     tpr_max = ctx.tile_count(0, world)
     tile_floats = capi.TILE * capi.TILE * 4
-    max_flight = 2 if multi else max(2, args.in_flight)
+    # the C++ multi-GPU loop keeps as many frames in flight as it has buffer sets (VR_MGPU_SLOTS, default 2)
+    n_slots = max(1, min(4, int(os.environ.get("VR_MGPU_SLOTS", "2"))))
+    max_flight = n_slots if (multi and backend == "rccl") else (2 if multi else max(2, args.in_flight))
     # context-owned streams probed to really run side by side (two arbitrary HIP streams may share a hardware queue and
     # serialise: vr_stream, include/vr.h)
     streams = [ctx.stream(i) for i in range(max_flight)]
@@ -374,7 +376,7 @@ def main():
         return dt, kt
 
     dt_serial, kt_serial = timed_leg(1, args.warmup, args.steps, min_events=20)
-    nbuf_over = min(args.in_flight, max_flight)
+    nbuf_over = max_flight if mg is not None else min(args.in_flight, max_flight)
     dt_over, kt_over = timed_leg(nbuf_over, args.warmup, args.steps)
 
     # composited samples / covered pixels / samples whose voxels were fetched, for this rank's share of the frame
@@ -428,7 +430,6 @@ def main():
     vol_bytes = sum(int(np.prod(v.GetSize())) * 16 for v in vols)
 
     if mg is not None:
-        n_slots = max(1, min(4, int(os.environ.get("VR_MGPU_SLOTS", "2"))))
         gpu_frames = [mg.download(w, W, H) for w in range(min(2, n_slots))] if rank == 0 else []
     else:
         gpu_frames = [f.cpu().numpy() for f in frames[:2]] if rank == 0 else []

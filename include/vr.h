@@ -185,9 +185,10 @@ int vr_tile_count(const vr_ctx* ctx, int rank, int world);
  * `d_tiles` as described above.  These are what a multi-rank host (RCCL gather) drives.
  * Up to FOUR renders may be in flight at a time, each on its own stream and into its own buffer (use
  * them in turn): the next frame fills the machine while the previous one's longest rays drain (two in
- * flight give 1.45x the frame rate of one on C3, three 1.5x).  The limit is enforced: a fifth enqueue
- * blocks the calling thread until the oldest of the four launches has finished (each launch owns one
- * of four record buffers, guarded by an event).  vr_volume_upload*, vr_volume_normalize / _gradient,
+ * flight give 1.45x the frame rate of one on C3, three 1.5x).  What is enforced is EIGHT launches: a
+ * ninth enqueue blocks the calling thread until the oldest of the eight has finished (each launch owns
+ * one of eight record buffers, guarded by an event), so a caller that keeps four frames in flight never
+ * waits for its oldest launch inside an enqueue.  vr_volume_upload*, vr_volume_normalize / _gradient,
  * vr_tf_upload*, vr_resize and vr_destroy drain the whole device first, so they are safe to call
  * while asynchronous renders are still in flight on the caller's streams.                          */
 int vr_render_async(vr_ctx* ctx, int variant, void* d_frame, void* stream);

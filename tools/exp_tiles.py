@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--tf", default="default")
     ap.add_argument("--flavours", default="0,6")
+    ap.add_argument("--worlds", default="1,2,4,8")
     a = ap.parse_args()
     import torch  # first: torch's HIP runtime has to initialise before libvr_hip.so's
     torch.cuda.init()
@@ -29,10 +30,10 @@ def main():
     app = host.Application(W, H, 0)
     variant, vols = wl.build_scene(app, a.workload, a.tf)
     ctx = app.context()
-    streams = [torch.cuda.Stream() for _ in range(4)]
+    streams = [ctx.stream(i) for i in range(4)]  # the context's own streams, probed to run side by side
     for fl in [int(x) for x in a.flavours.split(",")]:
         ctx.set_kernel_flavour(fl)
-        for world in (1, 2, 4, 8):
+        for world in [int(x) for x in a.worlds.split(",")]:
             worst, per_rank = 0.0, []
             for rank in range(world):
                 for _ in range(3):
@@ -49,15 +50,17 @@ def main():
 
             def burst(k, depth):
                 for i in range(k):
-                    ctx.render_tiles_async(variant, 0, world, bufs[i % depth].data_ptr(), streams[i % depth].cuda_stream)
+                    ctx.render_tiles_async(variant, 0, world, bufs[i % depth].data_ptr(), streams[i % depth])
                 torch.cuda.synchronize()
 
             res = []
             for depth in (2, 3, 4):
+                ctx.hint_frames_in_flight(depth)
                 burst(8, depth)
                 t0 = time.perf_counter()
                 burst(120, depth)
                 res.append((time.perf_counter() - t0) / 120 * 1e3)
+            ctx.hint_frames_in_flight(1)
             print(f"flavour {fl} (ran {ran}) world {world}: slowest rank's kernel {worst:.4f} ms; rank 0 with 2 / 3 / 4 in flight "
                   + " / ".join(f"{t:.4f}" for t in res) + " ms/frame   (ranks: " + " ".join(f"{t:.3f}" for t in per_rank) + ")", flush=True)
 

@@ -34,8 +34,10 @@ struct KernelRing {  // one (start, stop) event pair per render call, reused rou
 
 }  // namespace
 
-constexpr int kInFlight = 4;  // renders that may be in flight at a time (one stream and one output buffer each)
-constexpr int kOrderRing = 8;  // launch-order buffers: written behind launch k, read by launches k+3 and k+4 only
+constexpr int kInFlight = 8;  // launches that may be in flight at a time (record buffers used in turn; twice the streams, so that
+                               // a caller with four frames in flight never blocks on its oldest launch)
+constexpr int kStreams = 4;   // vr_stream(): streams for frames in flight
+constexpr int kOrderRing = 16;  // launch-order buffers: written behind launch k, read by launches k+3 .. k+6 only (see enqueue_render)
 
 struct vr_ctx {
     int device = 0;
@@ -92,7 +94,7 @@ struct vr_ctx {
     unsigned* h_chain = nullptr;  // pinned, one word per ring slot: longest ray chain + 1 of that launch (0 = not known yet)
     int frames_in_flight = 1;                 // vr_hint_frames_in_flight: frames the caller keeps in flight on different streams
     unsigned long long order_seq = 0;
-    hipStream_t flight[kInFlight] = {};  // vr_stream(): streams probed to run side by side (created on first use)
+    hipStream_t flight[kStreams] = {};  // vr_stream(): streams probed to run side by side (created on first use)
     int n_flight = 0;
     hipStream_t order_stream = nullptr;  // the sorts run here, behind their launch's event: never on a frame's critical path
     int order_mode = 1;  // 0 = launch the blocks in index order (VR_EXP_ORDER=0)
@@ -476,10 +478,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         P.block_counts = c->d_block_counts[cb];
         c->cnt_buf = cb;
-        // launch order: the most recent sort of a launch of the same shape that is three or four launches old -- a younger
-        // one may still be waiting for its launch to finish (the sorts run on a side stream behind their launches; waiting
-        // for one would put a bubble into this stream), an older one's buffer may be recycled under this launch; ordered
-        // behind it by its event (long complete by then)
+        // launch order: the most recent sort of a launch of the same shape that is three or four launches old (one or two
+        // more than the frames the caller says it keeps in flight, if that is more) -- a younger one may still be waiting
+        // for its launch to finish (the sorts run on a side stream behind their launches; waiting for one would put a bubble
+        // into this stream, and with four frames in flight it would chain this launch behind the one three before it), an
+        // older one's buffer may be recycled under this launch; ordered behind it by its event (long complete by then)
         const unsigned long long okey = ((unsigned long long)grid.x << 32) ^ ((unsigned long long)block.x << 20) ^
                                         ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
                                         ((unsigned long long)fl << 44) ^ (packed ? 1ull << 63 : 0ull);
@@ -487,8 +490,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const bool ordered = c->order_mode == 1 && !wtb && grid.x <= (unsigned)kOrderMaxBlocks && grid.x % 8u == 0;
         if (ordered) {
             const vr_ctx::OrderSlot* best = nullptr;
+            const unsigned long long age = (unsigned long long)(c->frames_in_flight + 1 > 3 ? c->frames_in_flight + 1 : 3);
             for (const auto& o : c->order_ring)
-                if (o.valid && o.key == okey && o.seq + 4 >= c->order_seq && o.seq + 3 <= c->order_seq && (!best || o.seq > best->seq))
+                if (o.valid && o.key == okey && o.seq + age + 1 >= c->order_seq && o.seq + age <= c->order_seq && (!best || o.seq > best->seq))
                     best = &o;
             if (best) {
                 VR_HIP(c, hipStreamWaitEvent(s, best->sorted, 0));
@@ -799,6 +803,13 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
         if (!hip_ok(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming), "hipEventCreate")) return bail(VR_ERR_HIP);
     for (auto& o : c->order_ring)
         if (!hip_ok(hipEventCreateWithFlags(&o.sorted, hipEventDisableTiming), "hipEventCreate")) return bail(VR_ERR_HIP);
+    // The sorts run on a stream of their own, default priority.  The runtime deals streams onto a handful of hardware queues
+    // per priority level, and a sort waits (a barrier in its queue) for a launch that is still running, so WHICH streams end up
+    // sharing a queue with this one matters: measured on this box, a high- or low-priority sort stream lets a third frame in
+    // flight overlap (a rank's eighth of C3: 0.142 -> 0.110 ms per frame, kernels alone) but costs the multi-GPU loop 50 us per
+    // frame (0.24 -> 0.29 ms one frame at a time; with a high-priority sort stream its gather stream, high priority too, meets
+    // the sorts' barriers), and the full C3 frame gains nothing from a third frame in flight either way (tools/exp_tiles.py,
+    // tools/exp_queues).
     if (!hip_ok(hipStreamCreateWithFlags(&c->order_stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(VR_ERR_HIP);
     if (hipHostMalloc((void**)&c->h_chain, kOrderRing * sizeof(unsigned), hipHostMallocDefault) == hipSuccess)
         std::memset(c->h_chain, 0, kOrderRing * sizeof(unsigned));
@@ -1204,14 +1215,14 @@ static bool streams_overlap(vr_ctx* c, hipStream_t a, hipStream_t b, hipEvent_t 
 
 void* vr_stream(vr_ctx* c, int index)
 {
-    if (!c || index < 0 || index >= kInFlight) return nullptr;
+    if (!c || index < 0 || index >= kStreams) return nullptr;
     if (c->n_flight == 0) {
         if (hipSetDevice(c->device) != hipSuccess) return nullptr;
         (void)hipGetLastError();
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return nullptr;
         // candidates are created one by one; one is kept if it overlaps with every stream kept so far (at most 12 tries)
-        for (int tries = 0; tries < 12 && c->n_flight < kInFlight; ++tries) {
+        for (int tries = 0; tries < 12 && c->n_flight < kStreams; ++tries) {
             hipStream_t s = nullptr;
             if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
             bool ok = true;
@@ -1230,7 +1241,7 @@ void* vr_stream(vr_ctx* c, int index)
 int vr_hint_frames_in_flight(vr_ctx* c, int frames)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (frames < 1 || frames > kInFlight) return fail(c, VR_ERR_INVALID_ARG, "vr_hint_frames_in_flight: 1 .. 4");
+    if (frames < 1 || frames > kStreams) return fail(c, VR_ERR_INVALID_ARG, "vr_hint_frames_in_flight: 1 .. 4");
     c->frames_in_flight = frames;
     return VR_OK;
 }
