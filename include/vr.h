@@ -212,6 +212,25 @@ int vr_render_tiles_async(vr_ctx* ctx, int variant, int rank, int world, void* d
  * W*H*4 frame `d_frame` (device).                                                                */
 int vr_unpack_tiles_async(vr_ctx* ctx, const void* d_gathered, int world, void* d_frame, void* stream);
 
+/* Several frames in ONE launch.  Replaces: nothing in the reference (it renders one frame per OnRender,
+ * App/src/Application.cpp:121-239); this is the throughput form for callers that know the next frames' cameras
+ * (turntables, offline sequences, and above all a multi-GPU run, where one rank's share of a frame is a launch far too
+ * short to fill a GPU: a rank's eighth of the 1080p frame keeps 9 % of the wavefront slots busy).  n_frames = 1 .. 4
+ * frames of the SAME scene (the volumes and tables currently bound) are marched by one grid -- frame f with
+ * uniforms[f] into d_frames[f] / d_tiles[f] (device, each W*H*4 floats / packed tiles as above).  The context's own
+ * uniforms (vr_set_uniforms) are neither used nor changed.  Every frame is bit-identical to what vr_render_async
+ * would have produced with the same uniforms; vr_last_counters reports the LAST frame of the launch.  One launch counts
+ * as one render in flight.                                                                                        */
+int vr_render_batch_async(vr_ctx* ctx, int variant, int n_frames, const vr_uniforms* uniforms, void* const* d_frames, void* stream);
+int vr_render_tiles_batch_async(vr_ctx* ctx, int variant, int rank, int world, int n_frames, const vr_uniforms* uniforms,
+                                void* const* d_tiles, void* stream);
+
+/* vr_unpack_tiles_async for gathered segments that lie `rank_stride_tiles` tiles apart (>= a segment) instead of back to
+ * back: after gathering n frames' segments at once rank r's tiles of frame f start at
+ * d_gathered + ((r * n + f) * tiles_per_rank_max) * 64*64*4 floats, so frame f is unpacked from the base of ITS first
+ * segment with rank_stride_tiles = n * tiles_per_rank_max.                                                        */
+int vr_unpack_tiles_strided_async(vr_ctx* ctx, const void* d_gathered, int world, int rank_stride_tiles, void* d_frame, void* stream);
+
 /* Replaces: reading back the colour attachment.  frag_rgba (W*H*4 floats, may be NULL) receives
  * the fragment shader output `dst` per pixel BEFORE output merge; pixels with no fragment = 0.
  * present_bgra8 (W*H*4 bytes, may be NULL) receives the presented pixel: blend

@@ -768,3 +768,91 @@ def test_context_streams_for_frames_in_flight(ctx):
     finally:
         for o in others:
             o.close()
+
+
+def _batch_uniforms(W, H, count, step):
+    """Four visibly different frames: camera, clip box, step count, debug mode."""
+    return [hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=0.6),
+            hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=1.4, pitch=-0.2, clip_x=(0.2, 0.1)),
+            hr.make_uniforms(W, H, steps_count=count // 2, step_size=step * 2, yaw=2.9, distance=1.6, toggles=(1, 0, 0, 0)),
+            hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=0.1, fragment_mode=2)]
+
+
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.VOLUME_MASK, capi.MULTI_CTRT])
+@pytest.mark.parametrize("flavour", [0, 1, 6, 10, 11])
+def test_frames_of_one_launch_equal_single_renders(ctx, variant, flavour):
+    """vr_render_batch_async: n = 1..4 frames of the same scene marched by ONE grid, each with its own uniforms and output
+    buffer, are bit-equal to vr_render with those uniforms (which the other tests pin to the oracle); the counters reported
+    are those of the launch's last frame."""
+    W, H = 136, 100
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(variant, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    us = _batch_uniforms(W, H, count, step)
+    ctx.set_kernel_flavour(0)
+    refs = [vt.gpu_render(ctx, variant, u, vols, tfs) for u in us]
+    others = [capi.Context(W, H, 0) for _ in range(4)]
+    try:
+        ctx.set_kernel_flavour(flavour)
+        for n in (1, 2, 3, 4):
+            for rot in (0, 1):   # which frame comes first (and last) varies
+                order = [(k + rot) % 4 for k in range(n)]
+                ctx.render_batch_async(variant, [vt.to_capi_uniforms(us[k]) for k in order],
+                                       [others[j].frame_device_ptr() for j in range(n)], ctx.stream(0))
+                comp = ctx.counters()[0]          # waits for the launch
+                assert comp == refs[order[-1]][2], (n, rot)
+                ctx.resize(W, H)                  # drains the device
+                for j, k in enumerate(order):
+                    got, _, _ = others[j].download()
+                    assert np.array_equal(vt.bits(got), vt.bits(refs[k][0])), (n, rot, j)
+    finally:
+        ctx.set_kernel_flavour(0)
+        for o in others:
+            o.close()
+
+
+def test_tile_shares_of_several_frames_in_one_launch(ctx):
+    """vr_render_tiles_batch_async: a rank's packed tiles of n frames from one launch equal vr_render_tiles' frame by frame."""
+    W, H = 256, 256   # 16 tiles; rank 1 of 2 owns 8 = 32768 pixels: fits a helper context's W x H frame buffer
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(capi.LIGHT, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    us = _batch_uniforms(W, H, count, step)[:3]
+    for i, v in enumerate(vols):
+        ctx.volume_upload(i, v)
+    for i, t in enumerate(tfs):
+        ctx.tf_upload(i, t[0], t[1])
+    refs = []
+    for u in us:
+        ctx.set_uniforms(vt.to_capi_uniforms(u))
+        ctx.render_tiles(capi.LIGHT, 1, 2)
+        refs.append(ctx.download_tiles(ctx.tile_count(1, 2))[0])
+    others = [capi.Context(W, H, 0) for _ in range(3)]
+    try:
+        ctx.render_tiles_batch_async(capi.LIGHT, 1, 2, [vt.to_capi_uniforms(u) for u in us], [o.frame_device_ptr() for o in others])
+        ctx.counters()
+        ctx.resize(W, H)
+        for o, ref in zip(others, refs):
+            raw, _, _ = o.download()
+            got = raw.reshape(-1)[: ref.size].reshape(ref.shape)
+            assert np.array_equal(vt.bits(got), vt.bits(ref))
+    finally:
+        for o in others:
+            o.close()
+
+
+def test_batch_arguments_are_checked(ctx):
+    W, H = 64, 64
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(capi.BASIC, n=16)
+    step, count = hr.stepping_params(16, 16, 16)
+    u = vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=count, step_size=step))
+    vt.gpu_render(ctx, capi.BASIC, hr.make_uniforms(W, H, steps_count=count, step_size=step), vols, tfs)
+    p = ctx.frame_device_ptr()
+    with pytest.raises(capi.VrError):
+        ctx.render_batch_async(capi.BASIC, [u] * 5, [p] * 5)        # more than four frames
+    with pytest.raises(capi.VrError):
+        ctx.render_batch_async(capi.BASIC, [u, u], [p, 0])          # a NULL output buffer
+    bad = vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=-1, step_size=step))
+    with pytest.raises(capi.VrError):
+        ctx.render_batch_async(capi.BASIC, [u, bad], [p, p])

@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "vr_volume_upload_device", "vr_volume_upload_raw16", "vr_volume_upload_raw32", "vr_volume_normalize",
     "vr_volume_precompute_gradient", "vr_volume_download", "vr_tf_upload", "vr_tf_upload_opacity", "vr_tf_upload_color", "vr_set_uniforms", "vr_render", "vr_render_tiles", "vr_tile_count",
     "vr_render_async", "vr_render_tiles_async", "vr_unpack_tiles_async", "vr_download", "vr_download_tiles",
+    "vr_render_batch_async", "vr_render_tiles_batch_async", "vr_unpack_tiles_strided_async",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
     "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream", "vr_hint_frames_in_flight",
 ]
@@ -94,6 +95,9 @@ def load() -> C.CDLL:
     lib.vr_render_async.argtypes = [vp, i32, vp, vp]
     lib.vr_render_tiles_async.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.vr_unpack_tiles_async.argtypes = [vp, vp, i32, vp, vp]
+    lib.vr_render_batch_async.argtypes = [vp, i32, i32, C.POINTER(Uniforms), C.POINTER(vp), vp]
+    lib.vr_render_tiles_batch_async.argtypes = [vp, i32, i32, i32, i32, C.POINTER(Uniforms), C.POINTER(vp), vp]
+    lib.vr_unpack_tiles_strided_async.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.vr_download.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
     lib.vr_download_tiles.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     lib.vr_last_timing.argtypes = [vp, fp, fp]
@@ -219,6 +223,24 @@ class Context:
 
     def unpack_tiles_async(self, d_gathered: int, world: int, d_frame: int = 0, stream: int = 0):
         self._chk(self.lib.vr_unpack_tiles_async(self.h, d_gathered, world, d_frame, stream))
+
+    def unpack_tiles_strided_async(self, d_gathered: int, world: int, rank_stride_tiles: int, d_frame: int = 0, stream: int = 0):
+        self._chk(self.lib.vr_unpack_tiles_strided_async(self.h, d_gathered, world, rank_stride_tiles, d_frame, stream))
+
+    @staticmethod
+    def _batch_args(uniforms, buffers):
+        n = len(uniforms)
+        assert n == len(buffers)
+        return n, (Uniforms * n)(*uniforms), (C.c_void_p * n)(*buffers)
+
+    def render_batch_async(self, variant: int, uniforms, d_frames, stream: int = 0):
+        """One launch, len(uniforms) frames (1..4) of the bound scene: frame f with uniforms[f] into d_frames[f]."""
+        n, us, bufs = self._batch_args(uniforms, d_frames)
+        self._chk(self.lib.vr_render_batch_async(self.h, variant, n, us, bufs, stream))
+
+    def render_tiles_batch_async(self, variant: int, rank: int, world: int, uniforms, d_tiles, stream: int = 0):
+        n, us, bufs = self._batch_args(uniforms, d_tiles)
+        self._chk(self.lib.vr_render_tiles_batch_async(self.h, variant, rank, world, n, us, bufs, stream))
 
     def download(self, present: bool = False):
         """Returns (frag[H,W,4] float32, bgra8[H,W,4] uint8 or None, composited_samples)."""

@@ -6,7 +6,7 @@
 
 // the same dispatch over the kernels compiled with fused multiply-adds (vr_fused.hip)
 namespace vrf {
-void launch_march(const vr::LaunchDesc& L, hipStream_t s, const vr::MarchParams& P);
+void launch_march(const vr::LaunchDesc& L, hipStream_t s, const vr::MarchBatch& B);
 }
 
 #include <cstdio>
@@ -102,6 +102,7 @@ struct vr_ctx {
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
     int cnt_blocks = 0;
+    size_t cnt_offset = 0;                     // ... and where in that buffer the records of its last frame start (u64 words)
     unsigned long long* h_counters = nullptr;  // pinned [3]
     Timing tm;
     KernelRing ring;
@@ -255,13 +256,48 @@ bool all_finite(const float* v, int n)
     return true;
 }
 
-// Enqueue one render on `s`.  out == nullptr -> ctx-owned buffer.
-int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, float4* out, hipStream_t s,
-                   bool frame_events)
+// the fields of a launch's parameters that come from the uniforms of ONE frame
+void fill_frame_params(MarchParams& P, const vr_uniforms& u)
+{
+    std::memcpy(P.proj_inv, u.proj_inv, sizeof P.proj_inv);
+    std::memcpy(P.view_inv, u.view_inv, sizeof P.view_inv);
+    hit_rectangle(u, P.W, P.H, P.rect);
+    P.fragment_mode = u.fragment_mode;
+    P.steps_count = u.steps_count;
+    P.step_size = u.step_size;
+    // IsInSampleCoords bounds, BasicVolumeApp.wgsl:73-74 (same f32 expressions as the shader)
+    P.bmin[0] = 0.0f + u.clip_x[0]; P.bmin[1] = 0.0f + u.clip_y[0]; P.bmin[2] = 0.0f + u.clip_z[0];
+    P.bmax[0] = 1.0f - u.clip_x[1]; P.bmax[1] = 1.0f - u.clip_y[1]; P.bmax[2] = 1.0f - u.clip_z[1];
+    P.toggle_varstep = u.toggles[0];
+    P.toggle_jitter = u.toggles[1];
+    for (int i = 0; i < 3; ++i) {
+        P.light_pos[i] = u.light_pos[i];
+        P.light_amb[i] = u.light_ambient[i];
+        P.light_dif[i] = u.light_diffuse[i];
+        P.camera_pos[i] = u.camera_pos[i];
+    }
+}
+
+// Enqueue one launch on `s`: ONE frame with the context's uniforms into `out` (nullptr -> ctx-owned buffer), or, with
+// batch_u / batch_out, n_frames (2 .. kBatchMax) frames of the same scene, each with its own uniforms and output buffer.
+int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, float4* out, hipStream_t s, bool frame_events,
+                   int n_frames = 1, const vr_uniforms* batch_u = nullptr, void* const* batch_out = nullptr)
 {
     if (variant < 0 || variant >= VR_VARIANT_COUNT) return fail(c, VR_ERR_INVALID_ARG, "vr_render: bad variant");
     if (world < 1 || rank < 0 || rank >= world) return fail(c, VR_ERR_INVALID_ARG, "vr_render: bad rank/world");
-    if (!c->have_uniforms) return fail(c, VR_ERR_NOT_READY, "vr_render: vr_set_uniforms has not been called");
+    if (n_frames < 1 || n_frames > kBatchMax) return fail(c, VR_ERR_INVALID_ARG, "vr_render: 1 .. 4 frames per launch");
+    if (batch_u) {
+        if (!batch_out) return fail(c, VR_ERR_INVALID_ARG, "vr_render: a batch needs its output buffers");
+        for (int f = 0; f < n_frames; ++f) {
+            if (!batch_out[f]) return fail(c, VR_ERR_INVALID_ARG, "vr_render: output buffer " + std::to_string(f) + " of the batch is NULL");
+            if (batch_u[f].steps_count < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: negative steps_count");
+        }
+        out = (float4*)batch_out[0];
+    } else {
+        if (n_frames != 1) return fail(c, VR_ERR_INVALID_ARG, "vr_render: several frames per launch need their uniforms");
+        if (!c->have_uniforms) return fail(c, VR_ERR_NOT_READY, "vr_render: vr_set_uniforms has not been called");
+    }
+    const vr_uniforms& u0 = batch_u ? batch_u[0] : c->u;
     int nvol, ntf;
     variant_needs(variant, &nvol, &ntf);
     bool off32 = true;
@@ -272,31 +308,15 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     for (int i = 0; i < ntf; ++i)
         if (!c->tf[i].opacity || !c->tf[i].color)
             return fail(c, VR_ERR_NOT_READY, "vr_render: TF slot " + std::to_string(i) + " is empty");
-    if (c->u.steps_count < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: negative steps_count");
+    if (u0.steps_count < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: negative steps_count");
     VR_HIP(c, hipSetDevice(c->device));
     (void)hipGetLastError();  // a stale error of somebody else's call must not be reported as a failed launch below
 
     MarchParams P;
     std::memset(&P, 0, sizeof P);
-    std::memcpy(P.proj_inv, c->u.proj_inv, sizeof P.proj_inv);
-    std::memcpy(P.view_inv, c->u.view_inv, sizeof P.view_inv);
     P.W = (int)c->W;
     P.H = (int)c->H;
-    hit_rectangle(c->u, P.W, P.H, P.rect);
-    P.fragment_mode = c->u.fragment_mode;
-    P.steps_count = c->u.steps_count;
-    P.step_size = c->u.step_size;
-    // IsInSampleCoords bounds, BasicVolumeApp.wgsl:73-74 (same f32 expressions as the shader)
-    P.bmin[0] = 0.0f + c->u.clip_x[0]; P.bmin[1] = 0.0f + c->u.clip_y[0]; P.bmin[2] = 0.0f + c->u.clip_z[0];
-    P.bmax[0] = 1.0f - c->u.clip_x[1]; P.bmax[1] = 1.0f - c->u.clip_y[1]; P.bmax[2] = 1.0f - c->u.clip_z[1];
-    P.toggle_varstep = c->u.toggles[0];
-    P.toggle_jitter = c->u.toggles[1];
-    for (int i = 0; i < 3; ++i) {
-        P.light_pos[i] = c->u.light_pos[i];
-        P.light_amb[i] = c->u.light_ambient[i];
-        P.light_dif[i] = c->u.light_diffuse[i];
-        P.camera_pos[i] = c->u.camera_pos[i];
-    }
+    fill_frame_params(P, u0);
     for (int i = 0; i < VR_MAX_VOLUMES; ++i) {
         P.vol[i] = c->vol[i];
         const bool plane = c->layout_mode != 1 && c->vol_dens[i] && c->vol[i].data;
@@ -338,7 +358,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         //    with one lane, 0.153 / 0.123 with two), unless the launch is too small to fill the machine at all.
         const long long px = (long long)tile_count(c, rank, world) * kTile * kTile;
         const int in_flight = c->frames_in_flight;  // the caller's hint (vr_hint_frames_in_flight)
-        const double rays_per_lane = (double)px * in_flight / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
+        const double rays_per_lane = (double)px * in_flight * n_frames / ((double)c->n_cus * 4.0 * 5.0 * 64.0);
         unsigned chain = 0;  // longest chain + 1 of the most recent launch of this scene shape whose sort has reported
         if (c->h_chain) {
             const unsigned long long skey = ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
@@ -361,7 +381,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     if (variant == VR_VARIANT_LIGHT_INSHADER && fl != 1 && fl != 4 && fl != 5) fl = 6;
     c->last_flavour = fl;
     bool can_skip = skip_variant && fl != 1 && fl != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
-                    c->tf_color_finite[0] && all_finite(c->u.light_pos, 12);
+                    c->tf_color_finite[0];
+    for (int f = 0; f < n_frames; ++f) can_skip = can_skip && all_finite(batch_u ? batch_u[f].light_pos : c->u.light_pos, 12);
     // the kernels index bricks with 24-bit multiplies and 32-bit byte offsets
     can_skip = can_skip && ((c->vol[sv].nx + 7) >> kBrickShift) * (long long)((c->vol[sv].ny + 7) >> kBrickShift) < (1 << 23);
     if (variant == VR_VARIANT_THREE_FILES) can_skip = can_skip && c->tf_color_finite[1] && c->tf_opacity_finite[1];
@@ -444,8 +465,10 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_begin, s));
     if (P.n_blocks > 0) {
         // flavours 2/3: LDS wave tiles (without / with skipping), lit shader only
-        const bool wtb = (fl == 2 || fl == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0 && c->arith == VR_ARITH_SEPARATE;
-        const int leap_mode = fl == 4 ? 1 : (fl == 5 ? 0 : (fl == 9 ? 2 : 3));
+        // (launches of several frames exist for the loop forms the default flavours use: plain, runs, depth-parallel)
+        const bool wtb = (fl == 2 || fl == 3) && variant == VR_VARIANT_LIGHT && P.fragment_mode == 0 && c->arith == VR_ARITH_SEPARATE &&
+                         n_frames == 1;
+        const int leap_mode = n_frames > 1 ? (fl == 5 ? 0 : 3) : (fl == 4 ? 1 : (fl == 5 ? 0 : (fl == 9 ? 2 : 3)));
         const int dp = (fl == 7 || fl == 10) ? 4 : ((fl == 8 || fl == 11) ? 2 : 0);
         // gradients on the fly (one-lane kernel, lit shader): the volume's .rgb is verified to be the central difference of
         // its .a, so the eight corners are derived from the density plane -- same bits, a quarter of the footprint
@@ -468,13 +491,14 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             const vr_ctx::OrderSlot& po = c->order_ring[(c->order_seq - kInFlight) % kOrderRing];
             if (po.valid && po.seq + kInFlight == c->order_seq) VR_HIP(c, hipStreamWaitEvent(s, po.sorted, 0));
         }
-        if (grid.x > c->block_counts_cap[cb]) {
+        const size_t n_records = (size_t)grid.x * (size_t)n_frames;  // every frame of the launch has its own records
+        if (n_records > c->block_counts_cap[cb]) {
             if (c->d_block_counts[cb]) (void)hipFree(c->d_block_counts[cb]);
             c->d_block_counts[cb] = nullptr;
             c->block_counts_cap[cb] = 0;
-            VR_HIP(c, hipMalloc(&c->d_block_counts[cb], (size_t)grid.x * kBlockRecord * sizeof(unsigned long long)));
-            VR_HIP(c, hipMemsetAsync(c->d_block_counts[cb], 0, (size_t)grid.x * kBlockRecord * sizeof(unsigned long long), s));
-            c->block_counts_cap[cb] = grid.x;
+            VR_HIP(c, hipMalloc(&c->d_block_counts[cb], n_records * kBlockRecord * sizeof(unsigned long long)));
+            VR_HIP(c, hipMemsetAsync(c->d_block_counts[cb], 0, n_records * kBlockRecord * sizeof(unsigned long long), s));
+            c->block_counts_cap[cb] = n_records;
         }
         P.block_counts = c->d_block_counts[cb];
         c->cnt_buf = cb;
@@ -513,8 +537,24 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.otf = otf;
             L.grid = grid;
             L.block = block;
-            if (c->arith == VR_ARITH_FUSED) vrf::launch_march(L, s, P);
-            else vr::launch_march(L, s, P);
+            // frame f of the launch: workgroups [f * grid.x, (f + 1) * grid.x), its own uniforms, output and records; the
+            // launch order (a heuristic of the shape) is shared
+            static thread_local MarchBatch B;
+            P.block_base = 0;
+            B.frame[0] = P;
+            for (int f = 1; f < n_frames; ++f) {
+                MarchParams& Pf = B.frame[f];
+                Pf = P;
+                fill_frame_params(Pf, batch_u[f]);
+                Pf.out = (float4*)batch_out[f];
+                Pf.block_counts = P.block_counts + (size_t)f * grid.x * kBlockRecord;
+                Pf.block_base = (unsigned)f * grid.x;
+            }
+            B.n_frames = (unsigned)n_frames;
+            B.blocks_per_frame = grid.x;
+            L.grid = dim3(grid.x * (unsigned)n_frames);
+            if (c->arith == VR_ARITH_FUSED) vrf::launch_march(L, s, B);
+            else vr::launch_march(L, s, B);
         }
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
@@ -550,8 +590,10 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
         ++c->ring.head;
         c->cnt_blocks = (int)grid.x;
+        c->cnt_offset = (size_t)(n_frames - 1) * grid.x * kBlockRecord;  // vr_last_counters: the LAST frame of the launch
     } else {
         c->cnt_blocks = 0;
+        c->cnt_offset = 0;
         if (frame_events) {
             VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
             VR_HIP(c, hipEventRecord(c->tm.ev_k1, s));
@@ -574,8 +616,8 @@ int fetch_counters(vr_ctx* c)
         // the launch may have been enqueued on a stream of the caller's that no longer exists: wait for the event recorded
         // behind it (owned by the context; other launches in flight are not waited for), then use the context's own stream
         VR_HIP(c, hipEventSynchronize(c->slot_done[c->cnt_buf]));
-        hipLaunchKernelGGL(sum_block_counts_kernel, dim3(1), dim3(256), 0, c->stream, c->d_block_counts[c->cnt_buf], c->cnt_blocks,
-                           c->d_counters);
+        hipLaunchKernelGGL(sum_block_counts_kernel, dim3(1), dim3(256), 0, c->stream, c->d_block_counts[c->cnt_buf] + c->cnt_offset,
+                           c->cnt_blocks, c->d_counters);
         VR_HIP(c, hipGetLastError());
         VR_HIP(c, hipMemcpyAsync(c->h_counters, c->d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                  c->stream));
@@ -1038,20 +1080,45 @@ int vr_render_tiles_async(vr_ctx* c, int variant, int rank, int world, void* d_t
     return enqueue_render(c, variant, rank, world, true, (float4*)d_tiles, s, false);
 }
 
-int vr_unpack_tiles_async(vr_ctx* c, const void* d_gathered, int world, void* d_frame, void* stream)
+int vr_render_batch_async(vr_ctx* c, int variant, int n_frames, const vr_uniforms* uniforms, void* const* d_frames, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!uniforms || !d_frames) return fail(c, VR_ERR_INVALID_ARG, "vr_render_batch_async: uniforms / buffers are NULL");
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return enqueue_render(c, variant, 0, 1, false, nullptr, s, false, n_frames, uniforms, d_frames);
+}
+
+int vr_render_tiles_batch_async(vr_ctx* c, int variant, int rank, int world, int n_frames, const vr_uniforms* uniforms,
+                                void* const* d_tiles, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!uniforms || !d_tiles) return fail(c, VR_ERR_INVALID_ARG, "vr_render_tiles_batch_async: uniforms / buffers are NULL");
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return enqueue_render(c, variant, rank, world, true, nullptr, s, false, n_frames, uniforms, d_tiles);
+}
+
+int vr_unpack_tiles_strided_async(vr_ctx* c, const void* d_gathered, int world, int rank_stride_tiles, void* d_frame, void* stream)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     if (!d_gathered || world < 1) return fail(c, VR_ERR_INVALID_ARG, "vr_unpack_tiles_async: bad arguments");
+    const int tpr = tile_count(c, 0, world);
+    if (rank_stride_tiles < tpr) return fail(c, VR_ERR_INVALID_ARG, "vr_unpack_tiles_strided_async: stride smaller than a segment");
     VR_HIP(c, hipSetDevice(c->device));
     (void)hipGetLastError();
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     float4* frame = d_frame ? (float4*)d_frame : c->d_frame;
-    int tpr = tile_count(c, 0, world);
     dim3 block(64, 4), grid((c->W + 63) / 64, (c->H + 3) / 4);
     hipLaunchKernelGGL(unpack_tiles_kernel, grid, block, 0, s, (const float4*)d_gathered, frame, (int)c->W, (int)c->H,
-                       tiles_x_of(c), world, tpr);
+                       tiles_x_of(c), world, rank_stride_tiles);
     VR_HIP(c, hipGetLastError());
     return VR_OK;
+}
+
+int vr_unpack_tiles_async(vr_ctx* c, const void* d_gathered, int world, void* d_frame, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (world < 1) return fail(c, VR_ERR_INVALID_ARG, "vr_unpack_tiles_async: bad arguments");
+    return vr_unpack_tiles_strided_async(c, d_gathered, world, tile_count(c, 0, world), d_frame, stream);
 }
 
 int vr_present_async(vr_ctx* c, const void* d_frame, void* d_bgra8, void* stream)
@@ -1185,7 +1252,7 @@ int vr_last_block_trace(vr_ctx* c, uint64_t* out, int capacity)
     VR_HIP(c, hipDeviceSynchronize());
     const int n = c->cnt_blocks < capacity ? c->cnt_blocks : capacity;
     if (n > 0)
-        VR_HIP(c, hipMemcpy(out, c->d_block_counts[c->cnt_buf], (size_t)n * kBlockRecord * sizeof(unsigned long long),
+        VR_HIP(c, hipMemcpy(out, c->d_block_counts[c->cnt_buf] + c->cnt_offset, (size_t)n * kBlockRecord * sizeof(unsigned long long),
                             hipMemcpyDeviceToHost));
     return c->cnt_blocks;
 }
@@ -1196,21 +1263,34 @@ int vr_last_kernel_flavour(vr_ctx* c)
     return c->last_flavour;
 }
 
-// true if kernels enqueued on a and b run concurrently (two 150 us single-wavefront spins take ~150 us, not ~300)
-static bool streams_overlap(vr_ctx* c, hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1)
+// Event-timed span of one 150 us single-wavefront spin on a and, if b is given, a second one on b right behind it.
+static float spin_span_ms(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1)
 {
     const unsigned long long ticks = 15000;  // 150 us of the 100 MHz clock
     (void)hipStreamSynchronize(a);
-    (void)hipStreamSynchronize(b);
+    if (b) (void)hipStreamSynchronize(b);
     (void)hipEventRecord(e0, a);
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks, (unsigned*)nullptr);
-    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks, (unsigned*)nullptr);
-    (void)hipEventRecord(e1, b);
+    if (b) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks, (unsigned*)nullptr);
+    (void)hipEventRecord(e1, b ? b : a);
     (void)hipStreamSynchronize(a);
-    (void)hipStreamSynchronize(b);
+    if (b) (void)hipStreamSynchronize(b);
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return true;  // cannot tell: assume the best
-    return ms < 0.24f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// true if kernels enqueued on a and b run concurrently: two spins take about as long as one (`one_ms`, measured on this
+// box a moment ago -- launch overheads differ between boxes and runs, a fixed limit misjudged them now and then), not twice
+static bool streams_overlap(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, float one_ms)
+{
+    for (int attempt = 0; attempt < 2; ++attempt) {  // a hiccup (page fault, clock ramp) must not cost a stream
+        const float ms = spin_span_ms(a, b, e0, e1);
+        if (getenv("VR_DEBUG_STREAMS")) fprintf(stderr, "[vr_stream] pair %p %p: %.3f ms (one spin %.3f ms)\n", (void*)a, (void*)b, ms, one_ms);
+        if (ms < 0.0f || one_ms <= 0.0f) return true;  // cannot tell: assume the best
+        if (ms < one_ms + 0.075f) return true;
+    }
+    return false;
 }
 
 void* vr_stream(vr_ctx* c, int index)
@@ -1221,15 +1301,28 @@ void* vr_stream(vr_ctx* c, int index)
         (void)hipGetLastError();
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return nullptr;
-        // candidates are created one by one; one is kept if it overlaps with every stream kept so far (at most 12 tries)
+        // candidates are created one by one; one is kept if it overlaps with every stream kept so far (at most 12 tries).
+        // Rejected candidates stay alive until the search is over: the runtime hands a stream that is destroyed and created
+        // again the very same hardware queue, and the search would try one queue twelve times.
+        float one_ms = -1.0f;
+        hipStream_t rejected[12];
+        int n_rejected = 0;
         for (int tries = 0; tries < 12 && c->n_flight < kStreams; ++tries) {
             hipStream_t s = nullptr;
             if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+            if (c->n_flight == 0) {  // the yardstick: one spin alone (the second measurement: the first one warms up)
+                (void)spin_span_ms(s, nullptr, e0, e1);
+                one_ms = spin_span_ms(s, nullptr, e0, e1);
+            }
             bool ok = true;
-            for (int k = 0; k < c->n_flight && ok; ++k) ok = streams_overlap(c, c->flight[k], s, e0, e1);
+            for (int k = 0; k < c->n_flight && ok; ++k) ok = streams_overlap(c->flight[k], s, e0, e1, one_ms);
+            // ... and with the stream of the launch-order sorts, whose barriers (a sort waits for its launch) would hold back
+            // the launches of a render stream that shares its queue
+            if (ok && c->order_stream) ok = streams_overlap(c->order_stream, s, e0, e1, one_ms);
             if (ok) c->flight[c->n_flight++] = s;
-            else (void)hipStreamDestroy(s);  // shares a hardware queue with a kept one
+            else rejected[n_rejected++] = s;  // shares a hardware queue with a kept one
         }
+        for (int k = 0; k < n_rejected; ++k) (void)hipStreamDestroy(rejected[k]);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         (void)hipGetLastError();

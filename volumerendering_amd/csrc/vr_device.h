@@ -73,7 +73,18 @@ struct MarchParams {
     // long blocks start at once and the short ones fill the machine at the end (speed only: a permutation of the blocks).
     const unsigned* order;
     float4* out;
-    unsigned long long* block_counts;  // [gridDim.x][kBlockRecord]: composited, covered, fetched, t0, t1, hw id
+    unsigned long long* block_counts;  // [blocks of this frame][kBlockRecord]: composited, covered, fetched, t0, t1, hw id
+    unsigned block_base;     // blockIdx.x of this frame's first workgroup (0 unless the launch carries several frames)
+};
+
+// One launch may carry up to kBatchMax frames of the same scene and shape (different uniforms, output and record buffers):
+// workgroups [f * blocks_per_frame, (f + 1) * blocks_per_frame) march frame f.  A rank's share of a frame on N GPUs, or a
+// small frame, is a launch too short to fill the machine; several of them in one launch do, without depending on how many
+// streams the runtime really runs side by side.  Passed by value: 4 x ~0.6 KB of the 4 KB kernarg segment.
+constexpr int kBatchMax = 4;
+struct MarchBatch {
+    MarchParams frame[kBatchMax];
+    unsigned n_frames, blocks_per_frame;
 };
 
 // What enqueue_render decided about one march launch; handed to launch_march of the arithmetic mode's translation unit

@@ -91,9 +91,10 @@ __device__ __forceinline__ void dp_blend_slot(int flags, v2f s_rg, v2f s_ba, v2f
     alive = alive && !cut && !left;
 }
 
-template <int V, bool OFF32, bool SKIP, int K, bool PIPE>
-__global__ __launch_bounds__(256) void march_dp_kernel(const MarchParams P)
+template <int V, bool OFF32, bool SKIP, int K, bool PIPE, bool BATCH = false>
+__global__ __launch_bounds__(256) void march_dp_kernel(const MarchBatch B)
 {
+    const MarchParams& P = frame_params<BATCH>(B);
     const unsigned long long t_start = wall_clock64();
     const PixelSlot slot = map_pixel_dp<K>(P);
     const int j = threadIdx.x & (K - 1);  // depth slot

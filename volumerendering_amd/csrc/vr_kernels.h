@@ -842,8 +842,21 @@ struct PixelSlot {
 // the logical block this workgroup works on (wave-uniform; P.order is a permutation of [0, gridDim.x))
 __device__ __forceinline__ int logical_block(const MarchParams& P)
 {
-    if (P.order == nullptr) return (int)blockIdx.x;
-    return (int)__builtin_amdgcn_readfirstlane((int)P.order[blockIdx.x]);
+    const unsigned b = blockIdx.x - P.block_base;  // block_base is a multiple of 8: b keeps blockIdx.x's XCD residue
+    if (P.order == nullptr) return (int)b;
+    return (int)__builtin_amdgcn_readfirstlane((int)P.order[b]);
+}
+
+// The parameters of the frame this workgroup belongs to (wave-uniform; three scalar compares, no division).  BATCH = false
+// (launches of ONE frame) addresses frame[0] statically: the compiler then loads the kernel arguments once, up front, as it
+// does for a plain by-value argument -- behind a computed address it re-loads them inside the march loop instead, which
+// costs a frame that waits for its longest ray chains 5 % (C3 one frame at a time: 0.58 -> 0.61 ms).
+template <bool BATCH>
+__device__ __forceinline__ const MarchParams& frame_params(const MarchBatch& B)
+{
+    if constexpr (!BATCH) return B.frame[0];
+    const unsigned b = blockIdx.x, n = B.blocks_per_frame;
+    return B.frame[(b >= n ? 1u : 0u) + (b >= 2u * n ? 1u : 0u) + (b >= 3u * n ? 1u : 0u)];
 }
 
 __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
@@ -1055,9 +1068,10 @@ __device__ __forceinline__ int steps_inside(f3 p, f3 step, float bx0, float by0,
 
 // OTF (V_LIGHT only): the corners' gradients are derived from the density plane (fetch_rgba_otf) instead of read from
 // the vec4 voxels; the host asks for it when the volume's .rgb is verified to be PreComputeGradient(false) of its .a.
-template <int V, bool OFF32, bool SKIP, int LEAP, bool OTF = false>
-__global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kernel(const MarchParams P)
+template <int V, bool OFF32, bool SKIP, int LEAP, bool OTF = false, bool BATCH = false>
+__global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kernel(const MarchBatch B)
 {
+    const MarchParams& P = frame_params<BATCH>(B);
     const unsigned long long t_start = wall_clock64();
     PixelSlot slot = map_pixel(P);
     float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -13,12 +13,23 @@
 namespace VR_KNS {
 
 template <int V, bool OTF = false>
-void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchParams& P)
+void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchBatch& B)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK || V == V_LIGHT_INSHADER);
-#define VR_LAUNCH(O, S, L) hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF>), grid, block, 0, s, P)
+    // launches that carry several frames (MarchBatch) exist for the loop forms the default flavours use: plain and runs
+    const bool batch = B.n_frames > 1;
+#define VR_LAUNCH(O, S, L)                                                                                             \
+    do {                                                                                                               \
+        if constexpr ((L) == 0 || (L) == 3) {                                                                          \
+            if (batch) {                                                                                               \
+                hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF, true>), grid, block, 0, s, B);                       \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF, false>), grid, block, 0, s, B);                              \
+    } while (0)
     if constexpr (kCanSkip) {
-        if (P.brick_dist) {
+        if (B.frame[0].brick_dist) {
             if (off32) {
                 if (leap == 2) VR_LAUNCH(true, true, 2);
                 else if (leap == 3) VR_LAUNCH(true, true, 3);
@@ -39,12 +50,16 @@ void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, 
 }
 
 template <int V, int K, bool PIPE>
-void launch_dp(bool off32, dim3 grid, dim3 block, hipStream_t s, const MarchParams& P)
+void launch_dp(bool off32, dim3 grid, dim3 block, hipStream_t s, const MarchBatch& B)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
-#define VR_LAUNCH_DP(O, S) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K, PIPE>), grid, block, 0, s, P)
+#define VR_LAUNCH_DP(O, S)                                                                                             \
+    do {                                                                                                               \
+        if (B.n_frames > 1) hipLaunchKernelGGL((march_dp_kernel<V, O, S, K, PIPE, true>), grid, block, 0, s, B);       \
+        else hipLaunchKernelGGL((march_dp_kernel<V, O, S, K, PIPE, false>), grid, block, 0, s, B);                     \
+    } while (0)
     if constexpr (kCanSkip) {
-        if (P.brick_dist) {
+        if (B.frame[0].brick_dist) {
             if (off32) VR_LAUNCH_DP(true, true);
             else VR_LAUNCH_DP(false, true);
             return;
@@ -55,7 +70,7 @@ void launch_dp(bool off32, dim3 grid, dim3 block, hipStream_t s, const MarchPara
 #undef VR_LAUNCH_DP
 }
 
-void launch_march(const LaunchDesc& L, hipStream_t s, const MarchParams& P)
+void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 {
     const int variant = L.variant;
     const bool off32 = L.off32, dp_pipe = L.dp_pipe, otf = L.otf;
@@ -63,52 +78,52 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchParams& P)
     const dim3 grid = L.grid, block = L.block;
 #if !VR_FUSED
         if (L.wtb) {
-            if (P.brick_dist) {
-                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, P);
-                else hipLaunchKernelGGL((march_wtb_light_kernel<false, true>), grid, dim3(256), 0, s, P);
+            if (B.frame[0].brick_dist) {
+                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, B);
+                else hipLaunchKernelGGL((march_wtb_light_kernel<false, true>), grid, dim3(256), 0, s, B);
             } else {
-                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, false>), grid, dim3(256), 0, s, P);
-                else hipLaunchKernelGGL((march_wtb_light_kernel<false, false>), grid, dim3(256), 0, s, P);
+                if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, false>), grid, dim3(256), 0, s, B);
+                else hipLaunchKernelGGL((march_wtb_light_kernel<false, false>), grid, dim3(256), 0, s, B);
             }
         } else
 #endif
         if (dp == 4) {
             switch (variant) {
-            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4, false>(off32, grid, block, s, P); break;
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 4, false>(off32, grid, block, s, B); break;
             case VR_VARIANT_LIGHT:
-                if (dp_pipe) launch_dp<V_LIGHT, 4, true>(off32, grid, block, s, P);
-                else launch_dp<V_LIGHT, 4, false>(off32, grid, block, s, P);
+                if (dp_pipe) launch_dp<V_LIGHT, 4, true>(off32, grid, block, s, B);
+                else launch_dp<V_LIGHT, 4, false>(off32, grid, block, s, B);
                 break;
-            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4, false>(off32, grid, block, s, P); break;
-            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4, false>(off32, grid, block, s, P); break;
-            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4, false>(off32, grid, block, s, P); break;
-            default: launch_dp<V_TF_CALIB, 4, false>(off32, grid, block, s, P); break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4, false>(off32, grid, block, s, B); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4, false>(off32, grid, block, s, B); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4, false>(off32, grid, block, s, B); break;
+            default: launch_dp<V_TF_CALIB, 4, false>(off32, grid, block, s, B); break;
             }
         } else if (dp == 2) {
             switch (variant) {
-            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2, false>(off32, grid, block, s, P); break;
+            case VR_VARIANT_BASIC: launch_dp<V_BASIC, 2, false>(off32, grid, block, s, B); break;
             case VR_VARIANT_LIGHT:
-                if (dp_pipe) launch_dp<V_LIGHT, 2, true>(off32, grid, block, s, P);
-                else launch_dp<V_LIGHT, 2, false>(off32, grid, block, s, P);
+                if (dp_pipe) launch_dp<V_LIGHT, 2, true>(off32, grid, block, s, B);
+                else launch_dp<V_LIGHT, 2, false>(off32, grid, block, s, B);
                 break;
-            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2, false>(off32, grid, block, s, P); break;
-            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2, false>(off32, grid, block, s, P); break;
-            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2, false>(off32, grid, block, s, P); break;
-            default: launch_dp<V_TF_CALIB, 2, false>(off32, grid, block, s, P); break;
+            case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2, false>(off32, grid, block, s, B); break;
+            case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2, false>(off32, grid, block, s, B); break;
+            case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2, false>(off32, grid, block, s, B); break;
+            default: launch_dp<V_TF_CALIB, 2, false>(off32, grid, block, s, B); break;
             }
         } else
         switch (variant) {
-        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, B); break;
         case VR_VARIANT_LIGHT:
-            if (otf) launch_variant<V_LIGHT, true>(off32, leap_mode, grid, block, s, P);
-            else launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, P);
+            if (otf) launch_variant<V_LIGHT, true>(off32, leap_mode, grid, block, s, B);
+            else launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, B);
             break;
-        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_ILLUSTRATIVE: launch_variant<V_ILLUSTRATIVE>(off32, leap_mode, grid, block, s, P); break;
-        case VR_VARIANT_LIGHT_INSHADER: launch_variant<V_LIGHT_INSHADER>(off32, leap_mode, grid, block, s, P); break;
-        default: launch_variant<V_TF_CALIB>(off32, leap_mode, grid, block, s, P); break;
+        case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, B); break;
+        case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, B); break;
+        case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, B); break;
+        case VR_VARIANT_ILLUSTRATIVE: launch_variant<V_ILLUSTRATIVE>(off32, leap_mode, grid, block, s, B); break;
+        case VR_VARIANT_LIGHT_INSHADER: launch_variant<V_LIGHT_INSHADER>(off32, leap_mode, grid, block, s, B); break;
+        default: launch_variant<V_TF_CALIB>(off32, leap_mode, grid, block, s, B); break;
         }
 }
 

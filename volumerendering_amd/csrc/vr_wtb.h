@@ -112,8 +112,9 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 template <bool OFF32, bool SKIP>
-__global__ __launch_bounds__(256) void march_wtb_light_kernel(const MarchParams P)
+__global__ __launch_bounds__(256) void march_wtb_light_kernel(const MarchBatch B)
 {
+    const MarchParams& P = frame_params<false>(B);
     // one tile per wavefront; the four wavefronts of the block never touch each other's region
     __shared__ float4 tiles[4 * kWtbCap];
     float4* const tile = tiles + (threadIdx.x >> 6) * kWtbCap;
