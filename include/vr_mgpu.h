@@ -69,6 +69,18 @@ vr_ctx* vr_mgpu_context(vr_mgpu* m, int local_rank);
  * volumes and tables currently set on each context.  Returns the buffer set (0 / 1) the frame will land in.        */
 int vr_mgpu_frame_async(vr_mgpu* m, int variant);
 
+/* Several frames per launch (vr_render_tiles_batch_async, include/vr.h): every local rank marches its tiles of n_frames
+ * (1..4) frames in ONE launch -- frame f with uniforms[f], the same array on every rank; the contexts' own uniforms are not
+ * used -- one gather carries all n_frames segments of a rank, the root un-permutes n_frames frames.  A rank's share of a
+ * frame is a launch too short to fill a GPU (an eighth of the 1080p frame keeps 9 % of the wavefront slots busy): this is
+ * the throughput form of the loop, at the price of n_frames frames of delay.  The first call with a larger n_frames drains
+ * the pipeline and re-sizes the buffer sets.  Returns the buffer set; frame f of the launch is then found with
+ * vr_mgpu_batch_frame_device_ptr / vr_mgpu_download_batch_frame (f = 0 is what vr_mgpu_frame_device_ptr /
+ * vr_mgpu_download return).  Collective: every rank must issue the same sequence of calls.                          */
+int vr_mgpu_frames_async(vr_mgpu* m, int variant, int n_frames, const vr_uniforms* uniforms);
+void* vr_mgpu_batch_frame_device_ptr(vr_mgpu* m, int which, int frame_in_launch);
+int vr_mgpu_download_batch_frame(vr_mgpu* m, int which, int frame_in_launch, float* frag_rgba);
+
 /* Block until every enqueued frame is complete (on the root: assembled in its frame buffer).                      */
 int vr_mgpu_wait(vr_mgpu* m);
 

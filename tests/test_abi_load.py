@@ -34,7 +34,7 @@ def test_multi_gpu_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     und = subprocess.run(["nm", "-D", "--undefined-only", mgpu.LIB_PATH], capture_output=True, text=True).stdout
-    for sym in ("ncclGather", "ncclCommInitRank", "ncclCommInitAll", "ncclGroupStart", "vr_render_tiles_async", "vr_unpack_tiles_async"):
+    for sym in ("ncclGather", "ncclCommInitRank", "ncclCommInitAll", "ncclGroupStart", "vr_render_tiles_async", "vr_render_tiles_batch_async", "vr_unpack_tiles_strided_async"):
         assert sym in und, sym
     assert "rccl" in subprocess.run(["ldd", mgpu.LIB_PATH], capture_output=True, text=True).stdout
 

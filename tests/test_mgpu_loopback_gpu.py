@@ -137,3 +137,34 @@ def test_pipelined_frames_land_in_their_buffer_sets(lib, n_slots, monkeypatch):
         m.wait()
         for slot, k in landed.items():
             assert np.array_equal(vt.bits(m.download(slot, W, H)), vt.bits(refs[k])), (slot, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_several_frames_per_launch(lib, world):
+    """vr_mgpu_frames_async: 1..4 frames (different cameras) per launch and rank, one gather for all of them, strided
+    un-permute: every assembled frame equals the single-GPU render of its camera; launches alternate between the buffer sets
+    and the buffer sets are re-sized on the way up."""
+    W, H = 200, 150
+    yaws = [0.2, 0.9, 1.7, 2.4, 3.0, 3.9, 4.5]
+    refs = [reference(W, H, capi.LIGHT, y) for y in yaws]
+    step, count = hr.stepping_params(24, 24, 24)
+    us = [vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=y)) for y in yaws]
+    with mgpu.MultiGpu.local(W, H, [0] * world, _lib=lib) as m:
+        for r in range(world):
+            scene(m.context(r), W, H, capi.LIGHT)
+        m.frame_async(capi.LIGHT)                       # the one-frame form still works beside it
+        sets = [(0, 1), (1, 3), (3, 7), (0, 4)]         # launches of 1, 2, 4 and 4 frames
+        landed = []
+        for lo, hi in sets:
+            landed.append((m.frames_async(capi.LIGHT, us[lo:hi]), lo, hi))
+        assert [b for b, _, _ in landed] == [1, 0, 1, 0]
+        m.wait()
+        for b, lo, hi in landed[-2:]:                   # the last launch into each buffer set is still there
+            for f in range(hi - lo):
+                got = m.download_batch_frame(b, f, W, H)
+                assert np.array_equal(vt.bits(got), vt.bits(refs[lo + f][0])), (b, f)
+        (comp, covered, _), _ = m.reduce()              # counters: the LAST frame of the last launch
+        assert comp == refs[3][1] and covered == refs[3][2]
+        with pytest.raises(capi.VrError):
+            m.frames_async(capi.LIGHT, us[:5])

@@ -17,7 +17,8 @@
 namespace {
 
 constexpr int kTilePx = 64;
-constexpr int kSlots = 4;  // buffer sets; vr_mgpu::slots of them are used (frames in flight, default 2, VR_MGPU_SLOTS)
+constexpr int kSlots = 4;  // buffer sets; vr_mgpu::slots of them are used (launches in flight, default 2, VR_MGPU_SLOTS)
+constexpr int kBatch = 4;  // frames one launch may carry (vr_render_tiles_batch_async)
 
 thread_local std::string g_create_error;
 
@@ -30,9 +31,9 @@ struct Rank {
     hipStream_t s_render[kSlots] = {}, s_comm = nullptr;
     hipEvent_t ev_render[kSlots] = {}, ev_done[kSlots] = {};
     bool used[kSlots] = {};
-    float* tiles[kSlots] = {};     // this rank's packed tiles (segment padded to the largest rank's)
-    float* gathered[kSlots] = {};  // root: world segments
-    float* frame[kSlots] = {};     // root: the assembled W x H frame
+    float* tiles[kSlots] = {};     // this rank's packed tiles (segment padded to the largest rank's), batch_cap frames of them
+    float* gathered[kSlots] = {};  // root: world x batch_cap segments
+    float* frame[kSlots] = {};     // root: batch_cap assembled W x H frames, back to back
     unsigned long long* d_red = nullptr;  // 4 x 8 bytes for vr_mgpu_reduce
 };
 
@@ -43,7 +44,8 @@ struct vr_mgpu {
     uint32_t W = 0, H = 0;
     size_t seg_floats = 0;  // floats per rank segment = max tiles per rank * 64 * 64 * 4
     std::vector<Rank> r;    // the ranks this process drives
-    int slots = 2;          // frames in flight (buffer sets in use)
+    int slots = 2;          // launches in flight (buffer sets in use)
+    int batch_cap = 1;      // frames per launch the buffer sets are sized for (grown on demand by vr_mgpu_frames_async)
     int exp_share = 1;      // experiment (VR_MGPU_EXP_SHARE=N, world of one only): render and gather only rank 0's share of an
                             // N-rank partition -- the timeline of one rank of an N-GPU run on a one-GPU box; frames are incomplete
     unsigned long long frame_no = 0;
@@ -79,26 +81,45 @@ int fail(vr_mgpu* m, int code, const std::string& msg)
         if (rc__ != VR_OK) return fail((m), rc__, std::string(#call) + ": " + vr_last_error((rk).ctx));                \
     } while (0)
 
+// (re)allocates the buffer sets of one rank for m->batch_cap frames per launch; the rank must be idle
+int alloc_buffers(vr_mgpu* m, Rank& k)
+{
+    MG_HIP(m, hipSetDevice(k.device));
+    const int gather_world = m->exp_share > 1 ? m->exp_share : m->world;
+    const size_t seg = (m->seg_floats ? m->seg_floats : 4) * (size_t)m->batch_cap;
+    const size_t frame_floats = (size_t)m->W * m->H * 4 * (size_t)m->batch_cap;
+    for (int b = 0; b < m->slots; ++b) {
+        if (k.tiles[b]) (void)hipFree(k.tiles[b]);
+        if (k.gathered[b]) (void)hipFree(k.gathered[b]);
+        if (k.frame[b]) (void)hipFree(k.frame[b]);
+        k.tiles[b] = k.gathered[b] = k.frame[b] = nullptr;
+        k.used[b] = false;
+        MG_HIP(m, hipMalloc(&k.tiles[b], seg * sizeof(float)));
+        MG_HIP(m, hipMemset(k.tiles[b], 0, seg * sizeof(float)));
+        if (k.rank == 0) {
+            MG_HIP(m, hipMalloc(&k.gathered[b], seg * (size_t)gather_world * sizeof(float)));
+            MG_HIP(m, hipMemset(k.gathered[b], 0, seg * (size_t)gather_world * sizeof(float)));
+            MG_HIP(m, hipMalloc(&k.frame[b], frame_floats * sizeof(float)));
+            MG_HIP(m, hipMemset(k.frame[b], 0, frame_floats * sizeof(float)));
+        }
+    }
+    MG_HIP(m, hipDeviceSynchronize());
+    return VR_OK;
+}
+
 // streams, events and buffers of one rank (its device must be current)
 int setup_rank(vr_mgpu* m, Rank& k)
 {
     MG_HIP(m, hipSetDevice(k.device));
-    const int gather_world = m->exp_share > 1 ? m->exp_share : m->world;
     for (int b = 0; b < m->slots; ++b) {
         // the context's own streams: probed to really run side by side (two arbitrary streams may share a hardware queue)
         k.s_render[b] = (hipStream_t)vr_stream(k.ctx, b);
         if (!k.s_render[b]) return fail(m, VR_ERR_HIP, "vr_stream: no render stream available");
         MG_HIP(m, hipEventCreateWithFlags(&k.ev_render[b], hipEventDisableTiming));
         MG_HIP(m, hipEventCreateWithFlags(&k.ev_done[b], hipEventDisableTiming));
-        MG_HIP(m, hipMalloc(&k.tiles[b], (m->seg_floats ? m->seg_floats : 4) * sizeof(float)));
-        MG_HIP(m, hipMemset(k.tiles[b], 0, (m->seg_floats ? m->seg_floats : 4) * sizeof(float)));
-        if (k.rank == 0) {
-            MG_HIP(m, hipMalloc(&k.gathered[b], (m->seg_floats ? m->seg_floats : 4) * (size_t)gather_world * sizeof(float)));
-            MG_HIP(m, hipMemset(k.gathered[b], 0, (m->seg_floats ? m->seg_floats : 4) * (size_t)gather_world * sizeof(float)));
-            MG_HIP(m, hipMalloc(&k.frame[b], (size_t)m->W * m->H * 4 * sizeof(float)));
-            MG_HIP(m, hipMemset(k.frame[b], 0, (size_t)m->W * m->H * 4 * sizeof(float)));
-        }
     }
+    int rc = alloc_buffers(m, k);
+    if (rc != VR_OK) return rc;
     {   // gather + un-permute are short and every frame waits for them: highest priority the device offers
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -253,37 +274,70 @@ vr_ctx* vr_mgpu_context(vr_mgpu* m, int local_rank)
 }
 const char* vr_mgpu_backend(const vr_mgpu* m) { return m ? m->backend.c_str() : ""; }
 
-int vr_mgpu_frame_async(vr_mgpu* m, int variant)
+// One launch per rank: n_frames frames (uniforms == nullptr: ONE frame with the uniforms set on each context).
+static int enqueue_frames(vr_mgpu* m, int variant, int n_frames, const vr_uniforms* uniforms)
 {
-    if (!m) return VR_ERR_INVALID_ARG;
     const int b = (int)(m->frame_no % (unsigned long long)m->slots);
     const int part_world = m->exp_share > 1 ? m->exp_share : m->world;
+    const size_t seg = m->seg_floats ? m->seg_floats : 4;
     // 1. every local rank renders its tiles into buffer set b (behind the gather that last read that buffer)
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
         if (k.used[b]) MG_HIP(m, hipStreamWaitEvent(k.s_render[b], k.ev_done[b], 0));
-        MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, part_world, k.tiles[b], k.s_render[b]));
+        if (uniforms) {
+            void* ptrs[kBatch];
+            for (int f = 0; f < n_frames; ++f) ptrs[f] = k.tiles[b] + (size_t)f * seg;
+            MG_VR(m, k, vr_render_tiles_batch_async(k.ctx, variant, k.rank, part_world, n_frames, uniforms, ptrs, k.s_render[b]));
+        } else {
+            MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, part_world, k.tiles[b], k.s_render[b]));
+        }
         MG_HIP(m, hipEventRecord(k.ev_render[b], k.s_render[b]));
         MG_HIP(m, hipStreamWaitEvent(k.s_comm, k.ev_render[b], 0));
     }
-    // 2. one gather: rank r's segment lands at gathered[b] + r * seg on the root.  Every rank's communication stream
-    //    carries the frames in the same order, so the collectives match up across ranks.
-    const size_t seg = m->seg_floats ? m->seg_floats : 4;
+    // 2. one gather: rank r's n_frames segments land back to back at gathered[b] + r * n_frames * seg on the root.  Every
+    //    rank's communication stream carries the launches in the same order, so the collectives match up across ranks.
     if (m->r.size() > 1) MG_NCCL(m, ncclGroupStart());
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
-        MG_NCCL(m, ncclGather(k.tiles[b], k.rank == 0 ? k.gathered[b] : nullptr, seg, ncclFloat, 0, k.comm, k.s_comm));
+        MG_NCCL(m, ncclGather(k.tiles[b], k.rank == 0 ? k.gathered[b] : nullptr, seg * (size_t)n_frames, ncclFloat, 0, k.comm, k.s_comm));
     }
     if (m->r.size() > 1) MG_NCCL(m, ncclGroupEnd());
-    // 3. the root scatters the segments into the frame; the buffer set is free again when that is done
+    // 3. the root scatters the segments into the frames; the buffer set is free again when that is done
+    const int tpr = (int)(seg / ((size_t)kTilePx * kTilePx * 4));
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
-        if (k.rank == 0) MG_VR(m, k, vr_unpack_tiles_async(k.ctx, k.gathered[b], part_world, k.frame[b], k.s_comm));
+        if (k.rank == 0)
+            for (int f = 0; f < n_frames; ++f)
+                MG_VR(m, k, vr_unpack_tiles_strided_async(k.ctx, k.gathered[b] + (size_t)f * seg, part_world, n_frames * tpr,
+                                                          k.frame[b] + (size_t)f * m->W * m->H * 4, k.s_comm));
         MG_HIP(m, hipEventRecord(k.ev_done[b], k.s_comm));
         k.used[b] = true;
     }
     ++m->frame_no;
     return b;
+}
+
+int vr_mgpu_frame_async(vr_mgpu* m, int variant)
+{
+    if (!m) return VR_ERR_INVALID_ARG;
+    return enqueue_frames(m, variant, 1, nullptr);
+}
+
+int vr_mgpu_frames_async(vr_mgpu* m, int variant, int n_frames, const vr_uniforms* uniforms)
+{
+    if (!m) return VR_ERR_INVALID_ARG;
+    if (!uniforms || n_frames < 1 || n_frames > kBatch) return fail(m, VR_ERR_INVALID_ARG, "vr_mgpu_frames_async: 1 .. 4 frames with their uniforms");
+    if (n_frames > m->batch_cap) {  // first launch of this size: drain, then size the buffer sets for it (collective by construction:
+                                    // every rank is given the same n_frames)
+        int rc = vr_mgpu_wait(m);
+        if (rc != VR_OK) return rc;
+        m->batch_cap = n_frames;
+        for (auto& k : m->r) {
+            rc = alloc_buffers(m, k);
+            if (rc != VR_OK) return rc;
+        }
+    }
+    return enqueue_frames(m, variant, n_frames, uniforms);
 }
 
 int vr_mgpu_wait(vr_mgpu* m)
@@ -297,27 +351,33 @@ int vr_mgpu_wait(vr_mgpu* m)
     return VR_OK;
 }
 
-void* vr_mgpu_frame_device_ptr(vr_mgpu* m, int which)
+void* vr_mgpu_batch_frame_device_ptr(vr_mgpu* m, int which, int frame_in_launch)
 {
-    if (!m || which < 0 || which >= m->slots) return nullptr;
+    if (!m || which < 0 || which >= m->slots || frame_in_launch < 0 || frame_in_launch >= m->batch_cap) return nullptr;
     for (auto& k : m->r)
-        if (k.rank == 0) return k.frame[which];
+        if (k.rank == 0) return k.frame[which] + (size_t)frame_in_launch * m->W * m->H * 4;
     return nullptr;
 }
 
-int vr_mgpu_download(vr_mgpu* m, int which, float* frag_rgba)
+void* vr_mgpu_frame_device_ptr(vr_mgpu* m, int which) { return vr_mgpu_batch_frame_device_ptr(m, which, 0); }
+
+int vr_mgpu_download_batch_frame(vr_mgpu* m, int which, int frame_in_launch, float* frag_rgba)
 {
-    if (!m || !frag_rgba || which < 0 || which >= m->slots) return VR_ERR_INVALID_ARG;
+    if (!m || !frag_rgba || which < 0 || which >= m->slots || frame_in_launch < 0 || frame_in_launch >= m->batch_cap)
+        return VR_ERR_INVALID_ARG;
     int rc = vr_mgpu_wait(m);
     if (rc != VR_OK) return rc;
     for (auto& k : m->r)
         if (k.rank == 0) {
             MG_HIP(m, hipSetDevice(k.device));
-            MG_HIP(m, hipMemcpy(frag_rgba, k.frame[which], (size_t)m->W * m->H * 4 * sizeof(float), hipMemcpyDeviceToHost));
+            MG_HIP(m, hipMemcpy(frag_rgba, k.frame[which] + (size_t)frame_in_launch * m->W * m->H * 4,
+                                (size_t)m->W * m->H * 4 * sizeof(float), hipMemcpyDeviceToHost));
             return VR_OK;
         }
     return fail(m, VR_ERR_NOT_READY, "vr_mgpu_download: this process does not drive the root rank");
 }
+
+int vr_mgpu_download(vr_mgpu* m, int which, float* frag_rgba) { return vr_mgpu_download_batch_frame(m, which, 0, frag_rgba); }
 
 int vr_mgpu_reduce(vr_mgpu* m, uint64_t counters_sum[3], double local_value, double* max_value)
 {

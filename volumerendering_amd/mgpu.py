@@ -15,7 +15,8 @@ ID_BYTES = 128
 
 ABI_SYMBOLS = ["vr_mgpu_unique_id", "vr_mgpu_create", "vr_mgpu_create_local", "vr_mgpu_destroy", "vr_mgpu_last_error",
                "vr_mgpu_world", "vr_mgpu_local_ranks", "vr_mgpu_context", "vr_mgpu_frame_async", "vr_mgpu_wait",
-               "vr_mgpu_frame_device_ptr", "vr_mgpu_download", "vr_mgpu_reduce", "vr_mgpu_backend"]
+               "vr_mgpu_frame_device_ptr", "vr_mgpu_download", "vr_mgpu_reduce", "vr_mgpu_backend", "vr_mgpu_frames_async",
+               "vr_mgpu_batch_frame_device_ptr", "vr_mgpu_download_batch_frame"]
 
 _lib = None
 
@@ -39,6 +40,10 @@ def bind(path: str) -> C.CDLL:
     lib.vr_mgpu_context.restype = vp
     lib.vr_mgpu_frame_async.argtypes = [vp, i32]
     lib.vr_mgpu_wait.argtypes = [vp]
+    lib.vr_mgpu_frames_async.argtypes = [vp, i32, i32, C.POINTER(capi.Uniforms)]
+    lib.vr_mgpu_batch_frame_device_ptr.argtypes = [vp, i32, i32]
+    lib.vr_mgpu_batch_frame_device_ptr.restype = vp
+    lib.vr_mgpu_download_batch_frame.argtypes = [vp, i32, i32, vp]
     lib.vr_mgpu_frame_device_ptr.argtypes = [vp, i32]
     lib.vr_mgpu_frame_device_ptr.restype = vp
     lib.vr_mgpu_download.argtypes = [vp, i32, vp]
@@ -114,6 +119,16 @@ class MultiGpu:
 
     def frame_async(self, variant: int) -> int:
         return self._chk(self.lib.vr_mgpu_frame_async(self.h, variant))
+
+    def frames_async(self, variant: int, uniforms) -> int:
+        """One launch per rank carrying len(uniforms) frames (1..4); returns the buffer set."""
+        n = len(uniforms)
+        return self._chk(self.lib.vr_mgpu_frames_async(self.h, variant, n, (capi.Uniforms * n)(*uniforms)))
+
+    def download_batch_frame(self, which: int, frame_in_launch: int, W: int, H: int) -> np.ndarray:
+        out = np.empty((H, W, 4), dtype=np.float32)
+        self._chk(self.lib.vr_mgpu_download_batch_frame(self.h, which, frame_in_launch, out.ctypes.data))
+        return out
 
     def wait(self):
         self._chk(self.lib.vr_mgpu_wait(self.h))
