@@ -11,10 +11,15 @@ At N > 1 the same frame is image-tile partitioned (64x64 tiles, tile t owned by 
 its tiles from its own replica of the volume and an RCCL gather over xGMI assembles the frame on rank 0
 ("strong" scaling: total work fixed).
 
-Two legs are timed in one run, W warm-up + exactly K timed frames each, bracketed by barrier + device synchronise:
+Three legs are timed in one run, W warm-up + exactly K timed frames each, bracketed by barrier + device synchronise:
     serial      one frame at a time (the reference's interactive loop, Application.cpp:332-379): latency
-    overlapped  two frames in flight on two streams (the next frame fills the SIMDs the longest rays of the previous
-                one leave idle): throughput.  `value` / `ms_per_step` are this leg's; the serial leg is in `serial`.
+    pipelined_one_frame_per_launch
+                two launches in flight on two streams, one frame each (the next frame fills the SIMDs the longest rays
+                of the previous one leave idle): the throughput leg of round 1 and early round 2, kept for comparison
+    overlapped  two launches in flight, FOUR frames per launch (vr_render_batch_async / vr_mgpu_frames_async: one grid
+                marches four frames, their workgroups interleaved so that the long ray chains of all four start first):
+                throughput, at eight frames of delay.  `value` / `ms_per_step` are this leg's.  Every frame is marched
+                in full and checked bit for bit against the one-at-a-time leg's frame.
 value = composited samples of the whole frame / wall time per frame.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
@@ -248,6 +253,9 @@ def main():
                     help="frames in flight in the overlapped leg (1 = that leg is a second serial leg)")
     ap.add_argument("--exp-mode", type=int, default=0, help="experiment: fragmentMode 1-4 (ray set-up only)")
     ap.add_argument("--exp-steps", type=int, default=-1, help="experiment: override stepsCount")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="throughput leg: frames marched by one launch (vr_render_batch_async / vr_mgpu_frames_async; 1..4, "
+                         "0 = 4).  The leg with one frame per launch is timed and reported beside it")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -325,14 +333,38 @@ def main():
             if rank == 0 else [None, None]
         frames = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
 
-    def run_frames(n_frames, nbuf):
+    # frames per launch of the throughput leg (the one-frame-at-a-time leg never batches)
+    part_world = max(world, int(os.environ.get("VR_MGPU_EXP_SHARE", "1"))) if multi else 1
+    fpl = max(1, min(4, args.frames_per_launch if args.frames_per_launch > 0 else 4))
+    if multi and mg is None:
+        fpl = 1  # (the gloo rehearsal renders frame by frame)
+    batch_frames = [[torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(fpl)] for _ in range(max_flight)] \
+        if (fpl > 1 and not multi) else []
+
+    def run_frames(n_frames, nbuf, fpl=1):
         if not multi:
+            if fpl > 1 and nbuf > 1:  # one launch carries fpl frames (same camera in this bench; each frame marched in full)
+                u, k, launch = app.uniforms(), 0, 0
+                while k < n_frames:
+                    n = min(fpl, n_frames - k)
+                    ctx.render_batch_async(variant, [u] * n, [t.data_ptr() for t in batch_frames[launch % nbuf][:n]], streams[launch % nbuf])
+                    k += n
+                    launch += 1
+                return
             for k in range(n_frames):
                 ctx.render_async(variant, frames[k % nbuf].data_ptr(), streams[k % nbuf])
             return
         if mg is not None:
             # the C++ loop: every rank renders its tiles, ncclGather, the root un-permutes; two buffer sets, so up to two
-            # frames are in flight -- nbuf = 1 waits for every frame before the next one is enqueued
+            # launches are in flight -- nbuf = 1 waits for every frame before the next one is enqueued
+            if fpl > 1 and nbuf > 1:
+                u, k = app.uniforms(), 0
+                while k < n_frames:
+                    n = min(fpl, n_frames - k)
+                    mg.frames_async(variant, [u] * n)
+                    k += n
+                mg.wait()
+                return
             for _ in range(n_frames):
                 mg.frame_async(variant)
                 if nbuf == 1:
@@ -354,19 +386,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_leg(nbuf, n_warm, n_steps, min_events=0):
+    def timed_leg(nbuf, n_warm, n_steps, min_events=0, fpl=1):
         """W warm-up + exactly K timed frames, barrier + synchronise on both sides; the MAX over ranks of the wall time.
         Returns (seconds, HIP-event kernel durations of the timed launches [+ extra serial frames up to min_events])."""
         ctx.hint_frames_in_flight(nbuf)  # what this leg's caller does: steers the default kernel choice (vr.h)
-        run_frames(n_warm, nbuf)
+        run_frames(n_warm, nbuf, fpl)
         sync_all()
         ctx.reset_kernel_times()
         t0 = time.perf_counter()
-        run_frames(n_steps, nbuf)
+        run_frames(n_steps, nbuf, fpl)
         sync_all()
         dt = time.perf_counter() - t0
         if n_steps < min_events:  # the median below wants >= 20 event-timed frames (outside the K-step region)
-            run_frames(min_events - n_steps, nbuf)
+            run_frames(min_events - n_steps, nbuf, fpl)
             sync_all()
         kt = ctx.kernel_times(min(max(n_steps, min_events), 256))
         if dist is not None:  # MAX over ranks
@@ -377,7 +409,13 @@ def main():
 
     dt_serial, kt_serial = timed_leg(1, args.warmup, args.steps, min_events=20)
     nbuf_over = max_flight if mg is not None else min(args.in_flight, max_flight)
-    dt_over, kt_over = timed_leg(nbuf_over, args.warmup, args.steps)
+    # two launches in flight, one frame each (round 1's and early round 2's throughput leg; kept for comparison) ...
+    dt_pipe, kt_pipe = timed_leg(nbuf_over, args.warmup, args.steps) if fpl > 1 else (None, None)
+    # ... and the throughput leg proper: two launches in flight, fpl frames per launch
+    dt_over, kt_over = timed_leg(nbuf_over, args.warmup, args.steps, fpl=fpl)
+    if batch_frames:  # the frames of the batched launches must equal the one-at-a-time leg's frame bit for bit
+        if not all(bool(torch.equal(t.view(torch.int32), frames[0].view(torch.int32))) for bs_ in batch_frames for t in bs_):
+            raise SystemExit("bench.py: a frame of a batched launch differs from the single-frame render")
 
     # composited samples / covered pixels / samples whose voxels were fetched, for this rank's share of the frame
     my_samples, my_covered, my_fetched = ctx.counters()
@@ -403,13 +441,22 @@ def main():
                 "kernel_events": int(len(kt))}
 
     serial, over = leg(dt_serial, kt_serial, 1), leg(dt_over, kt_over, nbuf_over)
+    pipelined = None
+    if dt_pipe is not None:
+        pipelined = leg(dt_pipe, kt_pipe, nbuf_over)
+        pipelined["launches_in_flight"], pipelined["frames_per_launch"] = nbuf_over, 1
+    over["launches_in_flight"] = nbuf_over
+    over["frames_per_launch"] = fpl
+    over["frames_in_flight"] = nbuf_over * fpl
+    if fpl > 1:  # one event pair per LAUNCH: the durations are those of launches that carry fpl frames each
+        over["kernel_ms_note"] = f"kernel_ms_* are per launch of {fpl} frames"
     # the other arithmetic mode, same scene, both legs (20 frames each; outside the K-step regions above)
     arith_ab = None
     if not multi:
         other = "separate" if args.arith == "fused" else "fused"
         ctx.set_arithmetic(1 if other == "fused" else 0)
         dt_s2, kt_s2 = timed_leg(1, 5, 20)
-        dt_o2, kt_o2 = timed_leg(nbuf_over, 5, 20)
+        dt_o2, kt_o2 = timed_leg(nbuf_over, 5, 20, fpl=fpl)
         cs2, _, fs2 = ctx.counters()
         arith_ab = {"arithmetic": other,
                     "serial": {"ms_per_step": round(dt_s2 / 20 * 1e3, 4), "kernel_ms_median": round(float(np.median(kt_s2)), 4),
@@ -430,7 +477,8 @@ def main():
     vol_bytes = sum(int(np.prod(v.GetSize())) * 16 for v in vols)
 
     if mg is not None:
-        gpu_frames = [mg.download(w, W, H) for w in range(min(2, n_slots))] if rank == 0 else []
+        # every frame of the last launch into each buffer set (the throughput leg ran last)
+        gpu_frames = [mg.download_batch_frame(w, f, W, H) for w in range(min(2, n_slots)) for f in range(fpl)] if rank == 0 else []
     else:
         gpu_frames = [f.cpu().numpy() for f in frames[:2]] if rank == 0 else []
     gpu_frame = gpu_frames[0] if gpu_frames else None
@@ -538,7 +586,9 @@ def main():
         "config": {
             "workload": f"{args.workload}: ct-phantom-{n} RGBA32F voxels, {W}x{H}, {vname} shader, TF {args.tf}, air {args.air}, "
                         f"step 1/{round(1 / step_size)} x {steps_count}, camera d=1.2 yaw=.6 pitch=.35",
-            "partition": part, "value_is": f"overlapped leg ({over['frames_in_flight']} frames in flight); one frame at a time in `serial`",
+            "partition": part,
+            "value_is": f"throughput leg: {nbuf_over} launches in flight x {fpl} frame(s) per launch, every frame marched in full; "
+                        "one frame at a time (the latency an interactive viewer sees) in `serial`",
             "composited_samples_per_frame": total_samples, "fetched_samples_per_frame": total_fetched,
             "covered_pixels": covered, "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
             "volume_layout": ("density plane for .a fetches" + (", corner gradients derived on the fly" if layout_flags & 4 else ""))
@@ -547,6 +597,8 @@ def main():
         "serial": serial, "overlapped": over, "roofline": roofline,
     }
     out["config"]["arithmetic"] = args.arith
+    if pipelined:
+        out["pipelined_one_frame_per_launch"] = pipelined
     if arith_ab:
         out["arith_ab"] = arith_ab
     if args.pmc_extra:

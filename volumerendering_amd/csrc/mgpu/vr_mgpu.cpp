@@ -29,7 +29,7 @@ struct Rank {
     bool own_ctx = false;
     ncclComm_t comm = nullptr;
     hipStream_t s_render[kSlots] = {}, s_comm = nullptr;
-    hipEvent_t ev_render[kSlots] = {}, ev_done[kSlots] = {};
+    hipEvent_t ev_render[kSlots] = {}, ev_gathered[kSlots] = {};
     bool used[kSlots] = {};
     float* tiles[kSlots] = {};     // this rank's packed tiles (segment padded to the largest rank's), batch_cap frames of them
     float* gathered[kSlots] = {};  // root: world x batch_cap segments
@@ -116,7 +116,7 @@ int setup_rank(vr_mgpu* m, Rank& k)
         k.s_render[b] = (hipStream_t)vr_stream(k.ctx, b);
         if (!k.s_render[b]) return fail(m, VR_ERR_HIP, "vr_stream: no render stream available");
         MG_HIP(m, hipEventCreateWithFlags(&k.ev_render[b], hipEventDisableTiming));
-        MG_HIP(m, hipEventCreateWithFlags(&k.ev_done[b], hipEventDisableTiming));
+        MG_HIP(m, hipEventCreateWithFlags(&k.ev_gathered[b], hipEventDisableTiming));
     }
     int rc = alloc_buffers(m, k);
     if (rc != VR_OK) return rc;
@@ -254,7 +254,7 @@ void vr_mgpu_destroy(vr_mgpu* m)
         for (int b = 0; b < kSlots; ++b) {
             // (s_render[] belong to the context)
             if (k.ev_render[b]) (void)hipEventDestroy(k.ev_render[b]);
-            if (k.ev_done[b]) (void)hipEventDestroy(k.ev_done[b]);
+            if (k.ev_gathered[b]) (void)hipEventDestroy(k.ev_gathered[b]);
             if (k.tiles[b]) (void)hipFree(k.tiles[b]);
             if (k.gathered[b]) (void)hipFree(k.gathered[b]);
             if (k.frame[b]) (void)hipFree(k.frame[b]);
@@ -280,10 +280,12 @@ static int enqueue_frames(vr_mgpu* m, int variant, int n_frames, const vr_unifor
     const int b = (int)(m->frame_no % (unsigned long long)m->slots);
     const int part_world = m->exp_share > 1 ? m->exp_share : m->world;
     const size_t seg = m->seg_floats ? m->seg_floats : 4;
-    // 1. every local rank renders its tiles into buffer set b (behind the gather that last read that buffer)
+    // 1. every local rank renders its tiles into buffer set b, behind the gather that last read that tile buffer (not behind
+    //    the un-permute that followed it: that one reads the gather buffer and writes the frames, which only the
+    //    communication stream touches, in order)
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
-        if (k.used[b]) MG_HIP(m, hipStreamWaitEvent(k.s_render[b], k.ev_done[b], 0));
+        if (k.used[b]) MG_HIP(m, hipStreamWaitEvent(k.s_render[b], k.ev_gathered[b], 0));
         if (uniforms) {
             void* ptrs[kBatch];
             for (int f = 0; f < n_frames; ++f) ptrs[f] = k.tiles[b] + (size_t)f * seg;
@@ -302,7 +304,11 @@ static int enqueue_frames(vr_mgpu* m, int variant, int n_frames, const vr_unifor
         MG_NCCL(m, ncclGather(k.tiles[b], k.rank == 0 ? k.gathered[b] : nullptr, seg * (size_t)n_frames, ncclFloat, 0, k.comm, k.s_comm));
     }
     if (m->r.size() > 1) MG_NCCL(m, ncclGroupEnd());
-    // 3. the root scatters the segments into the frames; the buffer set is free again when that is done
+    for (auto& k : m->r) {
+        MG_HIP(m, hipSetDevice(k.device));
+        MG_HIP(m, hipEventRecord(k.ev_gathered[b], k.s_comm));
+    }
+    // 3. the root scatters the segments into the frames
     const int tpr = (int)(seg / ((size_t)kTilePx * kTilePx * 4));
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
@@ -310,7 +316,6 @@ static int enqueue_frames(vr_mgpu* m, int variant, int n_frames, const vr_unifor
             for (int f = 0; f < n_frames; ++f)
                 MG_VR(m, k, vr_unpack_tiles_strided_async(k.ctx, k.gathered[b] + (size_t)f * seg, part_world, n_frames * tpr,
                                                           k.frame[b] + (size_t)f * m->W * m->H * 4, k.s_comm));
-        MG_HIP(m, hipEventRecord(k.ev_done[b], k.s_comm));
         k.used[b] = true;
     }
     ++m->frame_no;

@@ -483,6 +483,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         if (dp && P.n_tiles * (dp == 4 ? 256 : 128) > 16384) wpb = 4;
         dim3 block((unsigned)(64 * wpb));
         dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 256 : 128) / wpb : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel / map_pixel_dp
+        if (n_frames > 1 && grid.x % 8u != 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: launch shape cannot carry several frames");
         const int cb = (int)(c->launch_seq++ % (unsigned)kInFlight);
         // the slot's previous launch (kInFlight launches ago, possibly on another stream) must have finished before its
         // record buffer is written again or re-allocated: this is what bounds the launches in flight to kInFlight
@@ -537,10 +538,10 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.otf = otf;
             L.grid = grid;
             L.block = block;
-            // frame f of the launch: workgroups [f * grid.x, (f + 1) * grid.x), its own uniforms, output and records; the
-            // launch order (a heuristic of the shape) is shared
+            // frame f of the launch: every n_frames-th group of 8 workgroups (MarchBatch), its own uniforms, output and
+            // records; the launch order (a heuristic of the shape) is shared
             static thread_local MarchBatch B;
-            P.block_base = 0;
+            P.batch_n = (unsigned)n_frames;
             B.frame[0] = P;
             for (int f = 1; f < n_frames; ++f) {
                 MarchParams& Pf = B.frame[f];
@@ -548,10 +549,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 fill_frame_params(Pf, batch_u[f]);
                 Pf.out = (float4*)batch_out[f];
                 Pf.block_counts = P.block_counts + (size_t)f * grid.x * kBlockRecord;
-                Pf.block_base = (unsigned)f * grid.x;
             }
             B.n_frames = (unsigned)n_frames;
-            B.blocks_per_frame = grid.x;
             L.grid = dim3(grid.x * (unsigned)n_frames);
             if (c->arith == VR_ARITH_FUSED) vrf::launch_march(L, s, B);
             else vr::launch_march(L, s, B);

@@ -74,17 +74,21 @@ struct MarchParams {
     const unsigned* order;
     float4* out;
     unsigned long long* block_counts;  // [blocks of this frame][kBlockRecord]: composited, covered, fetched, t0, t1, hw id
-    unsigned block_base;     // blockIdx.x of this frame's first workgroup (0 unless the launch carries several frames)
+    unsigned batch_n;        // frames the launch carries (1 .. kBatchMax): see MarchBatch
 };
 
-// One launch may carry up to kBatchMax frames of the same scene and shape (different uniforms, output and record buffers):
-// workgroups [f * blocks_per_frame, (f + 1) * blocks_per_frame) march frame f.  A rank's share of a frame on N GPUs, or a
-// small frame, is a launch too short to fill the machine; several of them in one launch do, without depending on how many
-// streams the runtime really runs side by side.  Passed by value: 4 x ~0.6 KB of the 4 KB kernarg segment.
+// One launch may carry up to kBatchMax frames of the same scene and shape (different uniforms, output and record buffers).
+// A rank's share of a frame on N GPUs, or a small frame, is a launch too short to fill the machine; several of them in one
+// launch do, without depending on how many streams the runtime really runs side by side.  The frames are
+// interleaved in groups of 8 workgroups: group g = blockIdx.x / 8 belongs to frame g % n_frames and is that frame's group
+// g / n_frames -- so a workgroup keeps the XCD residue of its index within the frame, and the longest-first launch order
+// (MarchParams::order) holds across the whole launch: the long workgroups of EVERY frame start first.  (Frame after frame,
+// the last frame's long ray chains would start when the others' blocks have all been dispatched.)  Passed by value:
+// 4 x ~0.6 KB of the 4 KB kernarg segment.
 constexpr int kBatchMax = 4;
 struct MarchBatch {
     MarchParams frame[kBatchMax];
-    unsigned n_frames, blocks_per_frame;
+    unsigned n_frames;
 };
 
 // What enqueue_render decided about one march launch; handed to launch_march of the arithmetic mode's translation unit

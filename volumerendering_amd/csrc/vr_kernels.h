@@ -839,24 +839,30 @@ struct PixelSlot {
     bool in_launch;  // the block's tile exists (the grid is padded to 8 x 16 blocks)
 };
 
-// the logical block this workgroup works on (wave-uniform; P.order is a permutation of [0, gridDim.x))
+// group g of 8 workgroups -> (its frame, its group index within the frame) for a launch of n frames (MarchBatch)
+__device__ __forceinline__ unsigned batch_group(unsigned g, unsigned n)
+{
+    return n == 1 ? g : (n == 2 ? g >> 1 : (n == 3 ? g / 3u : g >> 2));
+}
+
+// the logical block this workgroup works on (wave-uniform; P.order is a permutation of the frame's block indices)
 __device__ __forceinline__ int logical_block(const MarchParams& P)
 {
-    const unsigned b = blockIdx.x - P.block_base;  // block_base is a multiple of 8: b keeps blockIdx.x's XCD residue
+    const unsigned b = (batch_group(blockIdx.x >> 3, P.batch_n) << 3) | (blockIdx.x & 7u);  // index within the frame
     if (P.order == nullptr) return (int)b;
     return (int)__builtin_amdgcn_readfirstlane((int)P.order[b]);
 }
 
-// The parameters of the frame this workgroup belongs to (wave-uniform; three scalar compares, no division).  BATCH = false
-// (launches of ONE frame) addresses frame[0] statically: the compiler then loads the kernel arguments once, up front, as it
-// does for a plain by-value argument -- behind a computed address it re-loads them inside the march loop instead, which
-// costs a frame that waits for its longest ray chains 5 % (C3 one frame at a time: 0.58 -> 0.61 ms).
+// The parameters of the frame this workgroup belongs to (wave-uniform).  BATCH = false (launches of ONE frame) addresses
+// frame[0] statically: the compiler then loads the kernel arguments once, up front, as it does for a plain by-value
+// argument -- behind a computed address it re-loads them inside the march loop instead, which costs a frame that waits for
+// its longest ray chains 5 % (C3 one frame at a time: 0.58 -> 0.61 ms).
 template <bool BATCH>
 __device__ __forceinline__ const MarchParams& frame_params(const MarchBatch& B)
 {
     if constexpr (!BATCH) return B.frame[0];
-    const unsigned b = blockIdx.x, n = B.blocks_per_frame;
-    return B.frame[(b >= n ? 1u : 0u) + (b >= 2u * n ? 1u : 0u) + (b >= 3u * n ? 1u : 0u)];
+    const unsigned g = blockIdx.x >> 3, n = B.n_frames;
+    return B.frame[g - batch_group(g, n) * n];
 }
 
 __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
