@@ -341,6 +341,11 @@ def main():
     batch_frames = [[torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(fpl)] for _ in range(max_flight)] \
         if (fpl > 1 and not multi) else []
 
+    if mg is not None and fpl > 1:  # size the loop's buffer sets for fpl frames per launch outside every timed region
+        with stdout_to_stderr():
+            mg.frames_async(variant, [app.uniforms()] * fpl)
+            mg.wait()
+
     def run_frames(n_frames, nbuf, fpl=1):
         if not multi:
             if fpl > 1 and nbuf > 1:  # one launch carries fpl frames (same camera in this bench; each frame marched in full)

@@ -21,8 +21,9 @@
  *                         resources are uploaded to every context (vr_mgpu_context(m, i)).
  *
  * Frames are pipelined: frame k+1 renders while frame k's tiles travel and are un-permuted (tile / gather / frame
- * buffer sets used in turn; two by default, 1..4 with VR_MGPU_SLOTS -- a rank's share of a frame is a short,
- * latency-bound launch, and more of them in flight raise the frame rate at the price of frames of delay).
+ * buffer sets used in turn; two by default, 1..4 with VR_MGPU_SLOTS).  A rank's share of a frame is a short,
+ * latency-bound launch; what fills the GPUs is several frames per launch (vr_mgpu_frames_async below), not more
+ * launches in flight: the runtime runs two or three of a process's streams side by side, no more.
  * vr_mgpu_frame_async never blocks the host on the GPU beyond the C ABI's own bound of four launches in flight;
  * vr_mgpu_wait drains the pipeline.  A caller that really keeps frames in flight says so on every rank's context
  * (vr_hint_frames_in_flight(ctx, 2)): a rank's share is a small launch, and the default choice of lanes per ray depends

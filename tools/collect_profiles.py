@@ -32,8 +32,13 @@ def main():
             continue
         json.dump(d, open(os.path.join(DST, f"r02_{name}.json"), "w"), indent=1)
         r = d["roofline"]
+        pl = d.get("pipelined_one_frame_per_launch")
         print(f"{name:18s} serial {d['serial']['kernel_ms_median']:.4f} / {d['serial']['ms_per_step']:.4f} ms ({d['serial']['value']:.0f})  "
-              f"overlapped {d['overlapped']['ms_per_step']:.4f} ms ({d['value']:.0f})  traffic {(r.get('traffic') or 0) / 1e9:.2f} GB")
+              + (f"pipelined 2x1 {pl['ms_per_step']:.4f} ms ({pl['value']:.0f})  " if pl else "")
+              + f"throughput {d['overlapped'].get('launches_in_flight', 2)}x{d['overlapped'].get('frames_per_launch', 1)} "
+              f"{d['overlapped']['ms_per_step']:.4f} ms ({d['value']:.0f}, {d['fps']:.0f} fps)  traffic {(r.get('traffic') or 0) / 1e9:.2f} GB  "
+              f"composited {d['config']['composited_samples_per_frame'] / 1e6:.1f} M fetched {d['config']['fetched_samples_per_frame'] / 1e6:.1f} M "
+              f"flavour {d['config'].get('kernel_flavour_resolved')}")
     for t, dst in (("trace", "r02_c3_overlapped_kernel_stats.csv"), ("trace_serial", "r02_c3_serial_kernel_stats.csv")):
         f = newest(os.path.join(SRC, t, "*", "*kernel_stats.csv"))
         if f:

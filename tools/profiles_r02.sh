@@ -29,6 +29,12 @@ for W in C1 C2 C4 C5; do
   python3 bench.py --workload $W --steps 50 --warmup 5 --no-regimes > $OUT/${W}_default.json 2> $OUT/${W}_default.err; echo "$W rc $?"
   python3 bench.py --workload $W --tf thin --steps 50 --warmup 5 --no-regimes --no-cpu-baseline --no-live-pmc > $OUT/${W}_thin.json 2> $OUT/${W}_thin.err; echo "$W thin rc $?"
 done
-VR_BENCH_SELF_GATHER=1 python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-regimes --no-live-pmc > $OUT/c3_selfgather.json 2> $OUT/c3_selfgather.err; echo "selfgather rc $?"
+VR_BENCH_SELF_GATHER=1 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-regimes --no-live-pmc > $OUT/c3_selfgather.json 2> $OUT/c3_selfgather.err; echo "selfgather rc $?"
+# rank 0's timeline of an N-rank run, rehearsed on this one GPU (VR_MGPU_EXP_SHARE: its share of the tiles, the gather of its
+# segment through RCCL, the un-permute of whole frames); steady state (400 frames) and the driver's 20-frame run
+for N in 2 4 8; do
+  VR_BENCH_SELF_GATHER=1 VR_MGPU_EXP_SHARE=$N python3 bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-regimes --no-live-pmc > $OUT/c3_share${N}.json 2> $OUT/c3_share${N}.err; echo "share $N rc $?"
+  VR_BENCH_SELF_GATHER=1 VR_MGPU_EXP_SHARE=$N python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-regimes --no-live-pmc > $OUT/c3_share${N}_k20.json 2> $OUT/c3_share${N}_k20.err; echo "share $N k20 rc $?"
+done
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default rc $?"
 echo done
