@@ -102,6 +102,7 @@ struct vr_ctx {
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
     int cnt_blocks = 0;
+    bool zskip = true;                         // per-step zero-opacity vote (VR_EXP_NO_ZSKIP=1 switches it off for A/B)
     size_t cnt_offset = 0;                     // ... and where in that buffer the records of its last frame start (u64 words)
     unsigned long long* h_counters = nullptr;  // pinned [3]
     Timing tm;
@@ -398,6 +399,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         P.bsy = (float)c->vol[sv].ny * 0.125f;
         P.bsz = (float)c->vol[sv].nz * 0.125f;
         P.tf_zero_prefix = c->tf_zero_prefix[0];
+        P.zskip_prefix = c->zskip ? P.tf_zero_prefix : -1;
         P.bricks = c->vol_bricks[sv];
         P.use_rgb = 0;
         if (variant == VR_VARIANT_VOLUME_MASK) {
@@ -857,6 +859,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     else
         c->h_chain = nullptr;  // (the choice of lanes per ray then goes by the launch size alone)
     if (const char* e = getenv("VR_EXP_ORDER")) c->order_mode = atoi(e);
+    if (const char* e = getenv("VR_EXP_NO_ZSKIP")) c->zskip = atoi(e) == 0;
     if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 3 * sizeof(unsigned long long), hipHostMallocDefault),
                 "hipHostMalloc"))

@@ -68,6 +68,7 @@ struct MarchParams {
     int bnx, bny, bnz;       // bricks per axis
     float bsx, bsy, bsz;     // n/8 per axis of vol[skip_vol] (exact in f32)
     int tf_zero_prefix;      // largest Z with opacity[0..Z] == 0 exactly (-1: none)
+    int zskip_prefix;        // the same for the per-step vote of sample_and_blend (-1 with VR_EXP_NO_ZSKIP: never skips)
     // Launch order of the logical blocks: workgroup blockIdx.x works on logical block order[blockIdx.x] (nullptr =
     // identity).  The host sorts the blocks of the previous frame by their longest ray chain, longest first, so that the
     // long blocks start at once and the short ones fill the machine at the end (speed only: a permutation of the blocks).

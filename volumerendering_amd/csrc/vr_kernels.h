@@ -771,10 +771,27 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     }
     return o;
 }
-template <int V, bool OFF32, bool OTF = false>
+// True if the opacity table yields exactly 0 for density d: both texels of the look-up lie in the table's zero prefix
+// (the index is tf_fetch's own; a NaN density gives a NaN opacity and is not "zero").
+__device__ __forceinline__ bool opacity_is_zero(const MarchParams& P, float d)
+{
+    const int jo = padded_texel(floorf(mad(d, (float)P.tf[0].res_o, -0.5f)), P.tf[0].res_o);
+    return d == d && jo <= P.zskip_prefix;
+}
+
+// ZSKIP (the host has verified what exact empty-space skipping needs: finite colour table and light, SKIP kernels only):
+// when the opacity of EVERY ray of the packet is exactly 0 at this step, the blend is the identity for all of them (rgb
+// finite, rgb * 0 = 0, dst + (1 - dst.a) * 0 = dst) and the table texels, the gradient, the shade and the blend are not
+// computed -- the cells of an active brick that lie in air, before the rays reach the body.  One vote per step.
+template <int V, bool OFF32, bool OTF = false, bool ZSKIP = false>
 __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst, f3 start, float ss)
 {
-    if constexpr (V == V_LIGHT) {
+    if constexpr (V == V_BASIC && ZSKIP) {
+        const float density = tex3_a<OFF32>(P.vol[0], p);
+        if (__ballot(!opacity_is_zero(P, density)) == 0) return;
+        const TfSample t = tf_lookup(P.tf[0], density);
+        blend(t.rgb, t.opacity, dst);
+    } else if constexpr (V == V_LIGHT) {
         // sample_src<V_LIGHT> + blend, written on (x, y) / (r, g) register pairs from the interpolation to the blend so
         // that the packed instructions need no shuffling; per component the operations and their order are those of
         // normalize3 / shade / blend.
@@ -783,6 +800,9 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         if constexpr (OTF) fetch_rgba_otf<OFF32>(P.vol[0], p, q, fx, fy, fz);
         else fetch_rgba<OFF32>(P.vol[0], p, q, fx, fy, fz);
         const v2f zw = interp_zw(q, fx, fy, fz);  // (gradient z, density)
+        if constexpr (ZSKIP) {
+            if (__ballot(!opacity_is_zero(P, zw.y)) == 0) return;
+        }
         const TfFetch tq = tf_fetch(P.tf[0], zw.y);
         const v2f gxy = interp_xy(q, fx, fy, fz);
 #if VR_FUSED
@@ -1264,7 +1284,7 @@ __global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kern
                                     blend(t.rgb, t.opacity, dst);
                                 }
                             } else {
-                                sample_and_blend<V, OFF32, OTF>(P, p, w, dst, ray.start, step_size);
+                                sample_and_blend<V, OFF32, OTF, SKIP>(P, p, w, dst, ray.start, step_size);
                             }
                             ++fetched;
                             ++blends;
