@@ -659,6 +659,57 @@ struct Src {
     f3 rgb;
     float a;
 };
+// The arithmetic of three shaders behind their fetches (sample_src fetches and calls these; sample_and_blend puts its vote
+// between the two).
+template <bool OFF32>
+__device__ __forceinline__ Src src_inshader(const MarchParams& P, f3 p, f3 w, float ss, float density)
+{
+    // BasicVolLightApp.wgsl:209-222 with :212 enabled; ComputeGradient :239-253.  dirs[k] * step = (step, 0, 0) ...:
+    // the products with 0 and the additions of the resulting zeros are kept (they are the shader's operations)
+    Src o;
+    TfSample t = tf_lookup(P.tf[0], density);
+    const float d1 = 1.0f * ss, d0 = 0.0f * ss;
+    const float rx = tex3_a<OFF32>(P.vol[0], mk3(p.x + d1, p.y + d0, p.z + d0)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d1, p.y - d0, p.z - d0));
+    const float ry = tex3_a<OFF32>(P.vol[0], mk3(p.x + d0, p.y + d1, p.z + d0)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d0, p.y - d1, p.z - d0));
+    const float rz = tex3_a<OFF32>(P.vol[0], mk3(p.x + d0, p.y + d0, p.z + d1)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d0, p.y - d0, p.z - d1));
+    const float l = length3(mk3(rx, ry, rz));
+    f3 g = mk3(0.0f, 0.0f, 0.0f);
+    if (l != 0.0f) g = mk3((-rx) / l, (-ry) / l, (-rz) / l);  // (NaN length: the division gives NaN, as in the shader)
+    f3 N = normalize3(g);  // normalize(vec3(0)) = NaN -> max(NaN, 0) = 0: ambient only
+    f3 s = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
+                 mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
+                 mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
+    o.rgb = mk3(t.rgb.x * s.x, t.rgb.y * s.y, t.rgb.z * s.z);
+    o.a = t.opacity;
+    return o;
+}
+__device__ __forceinline__ Src src_volume_mask(const MarchParams& P, f3 w, float4 mask, float rt, float4 ct)
+{
+    Src o;
+    TfSample trt = tf_lookup(P.tf[1], rt);
+    TfSample tct = tf_lookup(P.tf[0], ct.w);
+    f3 N = normalize3(mk3(ct.x, ct.y, ct.z));
+    f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(0.96f, 0.76f, 0.67f), mk3(1.0f, 1.0f, 1.0f), 1.5f, 0.5f);
+    o.rgb = mk3(tct.rgb.x * s.x, tct.rgb.y * s.y, tct.rgb.z * s.z);
+    o.a = tct.opacity;
+    if (mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) {
+        o.a = trt.opacity;
+        o.rgb = trt.rgb;
+    }
+    return o;
+}
+__device__ __forceinline__ Src src_three_files(const MarchParams& P, float ct, float rt)
+{
+    Src o;
+    TfSample tct = tf_lookup(P.tf[0], ct);
+    TfSample trt = tf_lookup(P.tf[1], rt);
+    float om = 1.0f - trt.opacity;
+    o.rgb = mk3(mad(trt.rgb.x, trt.opacity, tct.rgb.x * om), mad(trt.rgb.y, trt.opacity, tct.rgb.y * om),
+                mad(trt.rgb.z, trt.opacity, tct.rgb.z * om));
+    o.a = tct.opacity;
+    return o;
+}
+
 // (start = the ray's first position and dst_a = the opacity accumulated so far are read by the illustrative shader only,
 // ss = the ray's step size after the variable-step override by the in-shader gradient only)
 template <int V, bool OFF32, bool OTF = false>
@@ -681,46 +732,16 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
         o.rgb = mk3(t.rgb.x * s.x, t.rgb.y * s.y, t.rgb.z * s.z);
         o.a = t.opacity;
     } else if constexpr (V == V_LIGHT_INSHADER) {
-        // BasicVolLightApp.wgsl:209-222 with :212 enabled; ComputeGradient :239-253.  dirs[k] * step = (step, 0, 0) ...:
-        // the products with 0 and the additions of the resulting zeros are kept (they are the shader's operations)
-        float density = tex3_a<OFF32>(P.vol[0], p);
-        TfSample t = tf_lookup(P.tf[0], density);
-        const float d1 = 1.0f * ss, d0 = 0.0f * ss;
-        const float rx = tex3_a<OFF32>(P.vol[0], mk3(p.x + d1, p.y + d0, p.z + d0)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d1, p.y - d0, p.z - d0));
-        const float ry = tex3_a<OFF32>(P.vol[0], mk3(p.x + d0, p.y + d1, p.z + d0)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d0, p.y - d1, p.z - d0));
-        const float rz = tex3_a<OFF32>(P.vol[0], mk3(p.x + d0, p.y + d0, p.z + d1)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d0, p.y - d0, p.z - d1));
-        const float l = length3(mk3(rx, ry, rz));
-        f3 g = mk3(0.0f, 0.0f, 0.0f);
-        if (l != 0.0f) g = mk3((-rx) / l, (-ry) / l, (-rz) / l);  // (NaN length: the division gives NaN, as in the shader)
-        f3 N = normalize3(g);  // normalize(vec3(0)) = NaN -> max(NaN, 0) = 0: ambient only
-        f3 s = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
-                     mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
-                     mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
-        o.rgb = mk3(t.rgb.x * s.x, t.rgb.y * s.y, t.rgb.z * s.z);
-        o.a = t.opacity;
+        o = src_inshader<OFF32>(P, p, w, ss, tex3_a<OFF32>(P.vol[0], p));
     } else if constexpr (V == V_VOLUME_MASK) {
-        float4 mask = tex3_rgba<OFF32>(P.vol[0], p);
-        float rt = tex3_a<OFF32>(P.vol[1], p);
-        float4 ct = tex3_rgba<OFF32>(P.vol[2], p);
-        TfSample trt = tf_lookup(P.tf[1], rt);
-        TfSample tct = tf_lookup(P.tf[0], ct.w);
-        f3 N = normalize3(mk3(ct.x, ct.y, ct.z));
-        f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(0.96f, 0.76f, 0.67f), mk3(1.0f, 1.0f, 1.0f), 1.5f, 0.5f);
-        o.rgb = mk3(tct.rgb.x * s.x, tct.rgb.y * s.y, tct.rgb.z * s.z);
-        o.a = tct.opacity;
-        if (mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) {
-            o.a = trt.opacity;
-            o.rgb = trt.rgb;
-        }
+        const float4 mask = tex3_rgba<OFF32>(P.vol[0], p);
+        const float rt = tex3_a<OFF32>(P.vol[1], p);
+        const float4 ct = tex3_rgba<OFF32>(P.vol[2], p);
+        o = src_volume_mask(P, w, mask, rt, ct);
     } else if constexpr (V == V_THREE_FILES) {
-        float ct = tex3_a<OFF32>(P.vol[0], p);
-        float rt = tex3_a<OFF32>(P.vol[1], p);
-        TfSample tct = tf_lookup(P.tf[0], ct);
-        TfSample trt = tf_lookup(P.tf[1], rt);
-        float om = 1.0f - trt.opacity;
-        o.rgb = mk3(mad(trt.rgb.x, trt.opacity, tct.rgb.x * om), mad(trt.rgb.y, trt.opacity, tct.rgb.y * om),
-                    mad(trt.rgb.z, trt.opacity, tct.rgb.z * om));
-        o.a = tct.opacity;
+        const float ct = tex3_a<OFF32>(P.vol[0], p);
+        const float rt = tex3_a<OFF32>(P.vol[1], p);
+        o = src_three_files(P, ct, rt);
     } else if constexpr (V == V_MULTI_CTRT) {
         float4 ct = tex3_rgba<OFF32>(P.vol[0], p);
         float rt = tex3_a<OFF32>(P.vol[1], p);
@@ -843,6 +864,32 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         dst.z = mad(om, src_b, dst.z);
         dst.w = mad(om, opacity, dst.w);
     } else {
+        if constexpr (ZSKIP && (V == V_VOLUME_MASK || V == V_THREE_FILES || V == V_LIGHT_INSHADER)) {
+            // the same vote for the other shaders whose opacity is the CT table's alone: all the step's fetches are issued as
+            // sample_src issues them, so a packet that does sample waits no longer than before; a packet in air saves the
+            // table look-ups and the arithmetic (and, for the in-shader gradient, its six further density fetches)
+            if constexpr (V == V_VOLUME_MASK) {
+                const float4 mask = tex3_rgba<OFF32>(P.vol[0], p);
+                const float rt = tex3_a<OFF32>(P.vol[1], p);
+                const float4 ct = tex3_rgba<OFF32>(P.vol[2], p);
+                const bool inert = !(mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) && opacity_is_zero(P, ct.w);
+                if (__ballot(!inert) == 0) return;
+                const Src s = src_volume_mask(P, w, mask, rt, ct);
+                blend(s.rgb, s.a, dst);
+            } else if constexpr (V == V_THREE_FILES) {
+                const float ct = tex3_a<OFF32>(P.vol[0], p);
+                const float rt = tex3_a<OFF32>(P.vol[1], p);
+                if (__ballot(!opacity_is_zero(P, ct)) == 0) return;
+                const Src s = src_three_files(P, ct, rt);
+                blend(s.rgb, s.a, dst);
+            } else {
+                const float density = tex3_a<OFF32>(P.vol[0], p);
+                if (__ballot(!opacity_is_zero(P, density)) == 0) return;
+                const Src s = src_inshader<OFF32>(P, p, w, ss, density);
+                blend(s.rgb, s.a, dst);
+            }
+            return;
+        }
         const Src s = sample_src<V, OFF32, OTF>(P, p, w, start, dst.w, ss);
         blend(s.rgb, s.a, dst);
     }
