@@ -237,6 +237,21 @@ def test_skipping_with_hostile_values(ctx):
             ctx.set_kernel_flavour(flavour)
             frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
             assert same(frag, ref) and ns == n_ref, (variant, flavour)
+    # a lone -inf voxel in otherwise empty space: the brick maximum does not see it (everything else is larger), yet the
+    # samples around it interpolate to NaN / -inf and their opacity is NaN -- its brick must not be skipped
+    # (the same for a lone NaN or +inf anywhere in a brick: the flag of a NaN found by a lane other than lane 0 of the
+    # brick-maximum kernel used to get lost)
+    for bad, where in ((-np.inf, (3, 3, 3)), (np.nan, (3, 3, 3)), (np.nan, (7, 9, 2)), (np.inf, (13, 3, 3)), (np.nan, (15, 15, 15))):
+        lone = np.zeros((n, n, n, 4), dtype=f32)
+        lone[where[0], where[1], where[2], 3] = bad
+        lone[12, 11, 10, 3] = 0.4
+        for variant in (capi.BASIC, capi.LIGHT):
+            ref, n_ref, _ = ob.render(variant, u, [lone], [tf], W, H, nthreads=8)
+            assert np.isnan(ref).any()
+            for flavour in (0, 6, 11):
+                ctx.set_kernel_flavour(flavour)
+                frag, _, ns = vt.gpu_render(ctx, variant, u, [lone], [tf])
+                assert same(frag, ref) and ns == n_ref, (bad, where, variant, flavour)
     # a huge (finite) colour: rgb * 0 would still be 0, but rgb * shade may overflow -> skipping is disabled as well
     big = hr.default_color_tf(32).copy()
     big[5, 0] = f32(3.0e38)

@@ -385,19 +385,19 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                     c->tf_color_finite[0];
     for (int f = 0; f < n_frames; ++f) can_skip = can_skip && all_finite(batch_u ? batch_u[f].light_pos : c->u.light_pos, 12);
     // the kernels index bricks with 24-bit multiplies and 32-bit byte offsets
-    can_skip = can_skip && ((c->vol[sv].nx + 7) >> kBrickShift) * (long long)((c->vol[sv].ny + 7) >> kBrickShift) < (1 << 23);
+    can_skip = can_skip && ((c->vol[sv].nx + kBrickCells - 1) >> kBrickShift) * (long long)((c->vol[sv].ny + kBrickCells - 1) >> kBrickShift) < (1 << 23);
     if (variant == VR_VARIANT_THREE_FILES) can_skip = can_skip && c->tf_color_finite[1] && c->tf_opacity_finite[1];
     if (variant == VR_VARIANT_VOLUME_MASK)  // mask and CT must share one grid so that one brick index serves both
         can_skip = can_skip && c->vol_bricks[0] && c->vol[0].nx == c->vol[2].nx && c->vol[0].ny == c->vol[2].ny &&
                    c->vol[0].nz == c->vol[2].nz;
     if (can_skip) {
         P.skip_vol = sv;
-        P.bnx = (c->vol[sv].nx + 7) >> kBrickShift;
-        P.bny = (c->vol[sv].ny + 7) >> kBrickShift;
-        P.bnz = (c->vol[sv].nz + 7) >> kBrickShift;
-        P.bsx = (float)c->vol[sv].nx * 0.125f;
-        P.bsy = (float)c->vol[sv].ny * 0.125f;
-        P.bsz = (float)c->vol[sv].nz * 0.125f;
+        P.bnx = (c->vol[sv].nx + kBrickCells - 1) >> kBrickShift;
+        P.bny = (c->vol[sv].ny + kBrickCells - 1) >> kBrickShift;
+        P.bnz = (c->vol[sv].nz + kBrickCells - 1) >> kBrickShift;
+        P.bsx = (float)c->vol[sv].nx * kBrickInv;
+        P.bsy = (float)c->vol[sv].ny * kBrickInv;
+        P.bsz = (float)c->vol[sv].nz * kBrickInv;
         P.tf_zero_prefix = c->tf_zero_prefix[0];
         P.zskip_prefix = c->zskip ? P.tf_zero_prefix : -1;
         P.bricks = c->vol_bricks[sv];
@@ -639,7 +639,7 @@ int refresh_bricks(vr_ctx* c, int slot)
     c->vol_bricks[slot] = nullptr;
     c->merged_stale = true;
     ++c->brick_epoch;
-    const int bnx = (v.nx + 7) >> kBrickShift, bny = (v.ny + 7) >> kBrickShift, bnz = (v.nz + 7) >> kBrickShift;
+    const int bnx = (v.nx + kBrickCells - 1) >> kBrickShift, bny = (v.ny + kBrickCells - 1) >> kBrickShift, bnz = (v.nz + kBrickCells - 1) >> kBrickShift;
     const size_t nbricks = (size_t)bnx * bny * bnz;
     VR_HIP(c, hipMalloc(&c->vol_bricks[slot], nbricks * sizeof(float2)));
     hipLaunchKernelGGL(brick_max_kernel, dim3((unsigned)nbricks), dim3(64), 0, c->stream, v.data, v.nx, v.ny, v.nz, bnx, bny,

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchBatch B)
             // has at least 4 safe steps -> all of them advance by the same count; the ray passes steps
             // [base, base + mw), all inside the inert neighbourhood of slot 0 and inside the box
             int m = 1 << 30;
-            if (alive) m = (D >= 2) ? min((int)fminf(((float)D - 1.0625f) * leap_c, 64.0f), lim - my - 1) : 0;
+            if (alive) m = (D >= 2) ? min((int)fminf(((float)D - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - my - 1) : 0;
             if (__ballot(m < 4) == 0) {
                 int mw = 4;
                 if (__ballot(m < 8) == 0) {

@@ -793,11 +793,11 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     return o;
 }
 // True if the opacity table yields exactly 0 for density d: both texels of the look-up lie in the table's zero prefix
-// (the index is tf_fetch's own; a NaN density gives a NaN opacity and is not "zero").
+// (the index is tf_fetch's own; a NaN or infinite density gives a NaN opacity and is not "zero").
 __device__ __forceinline__ bool opacity_is_zero(const MarchParams& P, float d)
 {
     const int jo = padded_texel(floorf(mad(d, (float)P.tf[0].res_o, -0.5f)), P.tf[0].res_o);
-    return d == d && jo <= P.zskip_prefix;
+    return (d - d == 0.0f) && jo <= P.zskip_prefix;  // finite: an infinite density has a NaN weight, hence a NaN opacity
 }
 
 // ZSKIP (the host has verified what exact empty-space skipping needs: finite colour table and light, SKIP kernels only):
@@ -983,15 +983,15 @@ __device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
         // The clamp is taken in float (one v_med3_f32; a NaN comes out as 0 either way) and truncation of the clamped,
         // non-negative value is its floor: four instructions per axis.
         // (mad: the same rounding(s) as the cell's own coordinate p * n - 0.5 -- scaling by 1/8 commutes with either)
-        bx = (int)__builtin_amdgcn_fmed3f(mad(p.x, P.bsx, -0.0625f), 0.0f, (float)(P.bnx - 1));
-        by = (int)__builtin_amdgcn_fmed3f(mad(p.y, P.bsy, -0.0625f), 0.0f, (float)(P.bny - 1));
-        bz = (int)__builtin_amdgcn_fmed3f(mad(p.z, P.bsz, -0.0625f), 0.0f, (float)(P.bnz - 1));
+        bx = (int)__builtin_amdgcn_fmed3f(mad(p.x, P.bsx, -kBrickHalf), 0.0f, (float)(P.bnx - 1));
+        by = (int)__builtin_amdgcn_fmed3f(mad(p.y, P.bsy, -kBrickHalf), 0.0f, (float)(P.bny - 1));
+        bz = (int)__builtin_amdgcn_fmed3f(mad(p.z, P.bsz, -kBrickHalf), 0.0f, (float)(P.bnz - 1));
     } else {
         // (integer clamps: the 64-bit-address kernels sit at the register limit of five waves per SIMD and the float
         // form costs them four more)
-        bx = clampi((int)floorf(mad(p.x, P.bsx, -0.0625f)), 0, P.bnx - 1);
-        by = clampi((int)floorf(mad(p.y, P.bsy, -0.0625f)), 0, P.bny - 1);
-        bz = clampi((int)floorf(mad(p.z, P.bsz, -0.0625f)), 0, P.bnz - 1);
+        bx = clampi((int)floorf(mad(p.x, P.bsx, -kBrickHalf)), 0, P.bnx - 1);
+        by = clampi((int)floorf(mad(p.y, P.bsy, -kBrickHalf)), 0, P.bny - 1);
+        bz = clampi((int)floorf(mad(p.z, P.bsz, -kBrickHalf)), 0, P.bnz - 1);
     }
     return __mul24(__mul24(bz, P.bny) + by, P.bnx) + bx;  // < 2^24 bricks per axis pair: 24-bit multiplies are exact
 }
@@ -1101,7 +1101,7 @@ __device__ __forceinline__ int leap_apply(const LeapCoord& c, int m, float& out)
 __device__ __forceinline__ float leap_axis(float p, float s, float bs, int nb, int k, float inv_n)
 {
     if (s == 0.0f) return 1.0e9f;
-    const int b = clampi((int)floorf(mad(p, bs, -0.0625f)), 0, nb - 1);
+    const int b = clampi((int)floorf(mad(p, bs, -kBrickHalf)), 0, nb - 1);
     float room;
     if (s > 0.0f) {
         const int hi = b + k;  // last inert brick index in the direction of travel
@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kern
                         // of a packet stay at one step index, so their samples keep sharing cache lines.
                         int m = 0;
                         const bool far = __ballot(D < 2) == 0;  // (one vote decides for a packet that is sampling)
-                        if (far) m = min((int)fminf(((float)D - 1.0625f) * leap_c, 64.0f), lim - i - 1);
+                        if (far) m = min((int)fminf(((float)D - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - i - 1);
                         if (far && __ballot(m < 4) == 0) {
                             int mw = 4;
                             if (__ballot(m < 8) == 0) {
@@ -1411,20 +1411,23 @@ __global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kern
 }
 
 #if !VR_FUSED  // auxiliary kernels (no multiply-adds of the per-sample kind): compiled once, in namespace vr
-// One wavefront per brick: maximum of .a over the voxels [8b, min(8b+8, n-1)]^3 (NaN if any voxel is NaN).
+// One wavefront per brick of c = kBrickCells cells: maximum of .a over the voxels [c b, min(c b + c, n-1)]^3 (NaN if any
+// voxel is NaN or infinite).
 __global__ __launch_bounds__(64) void brick_max_kernel(const float4* __restrict__ vol, int nx, int ny, int nz, int bnx,
                                                        int bny, float2* __restrict__ out)
 {
     const int b = blockIdx.x;
     const int bx = b % bnx, by = (b / bnx) % bny, bz = b / (bnx * bny);
     const int x0 = bx << kBrickShift, y0 = by << kBrickShift, z0 = bz << kBrickShift;
-    const int ex = min(9, nx - x0), ey = min(9, ny - y0), ez = min(9, nz - z0);
+    const int ex = min(kBrickCells + 1, nx - x0), ey = min(kBrickCells + 1, ny - y0), ez = min(kBrickCells + 1, nz - z0);
     float m = -INFINITY, mc = -INFINITY;
     bool has_nan = false, has_nan_c = false;
     for (int t = threadIdx.x; t < ex * ey * ez; t += 64) {
         int lx = t % ex, ly = (t / ex) % ey, lz = t / (ex * ey);
         float4 v = vol[((size_t)(z0 + lz) * ny + (y0 + ly)) * nx + (x0 + lx)];
-        if (v.w != v.w) has_nan = true;
+        // NaN or +-inf: samples next to such a voxel interpolate to NaN (inf * 0, inf - inf) whatever the others hold, and a
+        // NaN density has a NaN opacity: the brick must stay active (a -inf would otherwise just lose the maximum)
+        if (!(v.w - v.w == 0.0f)) has_nan = true;
         else if (v.w > m) m = v.w;
         if (v.x != v.x || v.y != v.y || v.z != v.z) has_nan_c = true;
         else mc = fmaxf(mc, fmaxf(v.x, fmaxf(v.y, v.z)));
@@ -1433,8 +1436,12 @@ __global__ __launch_bounds__(64) void brick_max_kernel(const float4* __restrict_
     for (int off = 32; off > 0; off >>= 1) {
         m = fmaxf(m, __shfl_down(m, off, 64));
         mc = fmaxf(mc, __shfl_down(mc, off, 64));
-        has_nan = has_nan || (__shfl_down((int)has_nan, off, 64) != 0);
-        has_nan_c = has_nan_c || (__shfl_down((int)has_nan_c, off, 64) != 0);
+        // (every lane takes part in every shuffle: behind a short-circuiting `||` a lane that has already seen a NaN would
+        // sit the shuffle out, and the lane reading from it would get nothing -- the flag of a NaN found by any lane but
+        // lane 0 was lost that way until round 2, and a brick holding nothing else but that voxel was skipped)
+        const int other = __shfl_down((int)has_nan, off, 64), other_c = __shfl_down((int)has_nan_c, off, 64);
+        has_nan = has_nan || other != 0;
+        has_nan_c = has_nan_c || other_c != 0;
     }
     if (threadIdx.x == 0) out[b] = make_float2(has_nan ? NAN : m, has_nan_c ? NAN : mc);
 }
