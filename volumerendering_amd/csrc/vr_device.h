@@ -69,7 +69,7 @@ struct MarchParams {
     int rect[4];             // x0, y0, x1, y1 (inclusive): no ray outside this pixel rectangle can hit the box
     int n_blocks;            // logical blocks = n_tiles * kBlocksPerTile (grid is padded to a multiple of 8)
     // exact empty-space skipping (BASIC / LIGHT / THREE_FILES): per-brick maximum density of vol[0] over the
-    // 9x9x9 voxels an 8x8x8 block of base cells can touch, and the length of the opacity table's zero prefix
+    // (c+1)^3 voxels a brick of c^3 base cells can touch (c = kBrickCells), and the length of the opacity table's zero prefix
     const float2* bricks;    // nullptr = disabled; per brick: x = max of vol[skip_vol].a, y = max(r,g,b) of the mask
                              // (y is filled from vol[0]'s bricks for VOLUME_MASK and is 0 otherwise)
     int use_rgb;             // VOLUME_MASK: a brick is inert only if its mask record y <= 0
@@ -77,7 +77,7 @@ struct MarchParams {
                                       // distance k-1 is inert too (capped); rebuilt when the volume / opacity table change
     int skip_vol;            // which volume carries the density that drives the opacity (0, or 2 for VOLUME_MASK)
     int bnx, bny, bnz;       // bricks per axis
-    float bsx, bsy, bsz;     // n/8 per axis of vol[skip_vol] (exact in f32)
+    float bsx, bsy, bsz;     // n / kBrickCells per axis of vol[skip_vol] (exact in f32)
     int tf_zero_prefix;      // largest Z with opacity[0..Z] == 0 exactly (-1: none)
     int zskip_prefix;        // the same for the per-step vote of sample_and_blend (-1 with VR_EXP_NO_ZSKIP: never skips)
     // Launch order of the logical blocks: workgroup blockIdx.x works on logical block order[blockIdx.x] (nullptr =

@@ -966,7 +966,7 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
     return s;
 }
 
-// Exact empty-space test for the 8x8x8-cell brick that contains the base cell of p (vol[0]).
+// Exact empty-space test for the brick (kBrickCells^3 cells) that contains the base cell of p (vol[0]).
 // A brick whose maximum density bm (over every voxel its cells can touch) maps into the zero prefix of the
 // opacity table yields opacity == 0 exactly for every sample inside it, and blending (rgb*0, 0) leaves dst
 // bit-identical (rgb is finite: the host checks tables and light).  Interpolated densities can exceed bm by a
@@ -975,9 +975,9 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
 template <bool FMED = true>
 __device__ __forceinline__ int brick_of(const MarchParams& P, f3 p)
 {
-    // brick coordinate of the base cell: clamp(floor(p*n - 0.5), 0, n-1) >> 3.  Scaling by 1/8 is exact and commutes
-    // with f32 rounding, and floor(floor(x)/8) == floor(x/8), so this is the same integer as
-    // clamp(floor(p*(n/8) - 1/16), 0, (n-1) >> 3).
+    // brick coordinate of the base cell: clamp(floor(p*n - 0.5), 0, n-1) >> kBrickShift.  Scaling by 1/c (c = kBrickCells, a
+    // power of two) is exact and commutes with f32 rounding, and floor(floor(x)/c) == floor(x/c), so this is the same
+    // integer as clamp(floor(p*(n/c) - 1/(2c)), 0, (n-1) >> kBrickShift).
     int bx, by, bz;
     if constexpr (FMED) {
         // The clamp is taken in float (one v_med3_f32; a NaN comes out as 0 either way) and truncation of the clamped,
