@@ -286,13 +286,14 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
 
 /* Kernel flavour for A/B measurements.  All flavours are bit-identical in output and in the sample counts.
  *   0  default: exact empty-space skipping + wave-uniform runs through inert bricks; lanes per ray chosen from
- *      what will be on the machine -- the size of the launch times the frames the caller keeps in flight
- *      (vr_hint_frames_in_flight) -- and from the longest ray chain of an earlier launch of the same scene: one lane
+ *      what will be on the machine -- the size of the launch (frames per launch included) times the launches the
+ *      caller keeps in flight (vr_hint_frames_in_flight) -- and from the longest ray chain of an earlier launch of the same scene: one lane
  *      per ray when the machine is full of rays or the chains are short, two or four when the frame would otherwise
  *      wait for its longest rays (small frames, one GPU's share of the tiles)
  *   1  one lane per ray, no empty-space skipping (every composited sample is fetched)
  *   2 / 3  LDS wave tiles without / with skipping (lit shader only; others fall back to 1 / 6)
  *   4  skipping + closed-form leaping (f32 accumulation as integer arithmetic on the bit patterns)
+ *      (launches of several frames exist for the plain, run and depth-parallel loop forms: there 2 runs as 1 and 3 / 4 / 9 as 6)
  *   5  skipping alone, one step per iteration
  *   6  one lane per ray (forced), 7  four lanes per ray (forced), 8  two lanes per ray (forced)
  *   9  one lane per ray with the next step's corner loads software-pipelined behind the shading
