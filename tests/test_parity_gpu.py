@@ -871,3 +871,25 @@ def test_batch_arguments_are_checked(ctx):
     bad = vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=-1, step_size=step))
     with pytest.raises(capi.VrError):
         ctx.render_batch_async(capi.BASIC, [u, bad], [p, p])
+
+
+def test_kernel_times_from_the_launch_records_agree_with_events(ctx):
+    """vr_kernel_times: launches with a sort behind them are timed from their own workgroup records (first start .. last end,
+    100 MHz device clock) instead of two timing events on the frame's stream; vr_render's event pair (vr_last_timing) brackets
+    the same launch and must agree."""
+    W, H = 320, 240
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(capi.LIGHT, n=48)
+    step, count = hr.stepping_params(48, 48, 48)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
+    vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+    ctx.reset_kernel_times()
+    ev = []
+    for _ in range(6):
+        ctx.render(capi.LIGHT)
+        ev.append(ctx.last_timing()[0])
+    kt = ctx.kernel_times(6)
+    assert len(kt) == 6 and all(t > 0.0 for t in kt)
+    for a, b in zip(kt, ev):
+        # the event pair brackets the records' span: it adds the dispatch ramp and the events' own latency (some 10-30 us)
+        assert a < b + 0.005 and b - a < 0.05, (kt, ev)

@@ -91,6 +91,8 @@ struct vr_ctx {
         unsigned long long scene_key = 0;  // what the launch rendered, whatever kernel form it took (the chain length's key)
         bool valid = false;
     } order_ring[kOrderRing];
+    unsigned long long* h_span = nullptr;  // pinned, kRing words: duration of launch q in 100 MHz ticks + 1, from its records (0 = not known)
+    bool ring_events[kRing] = {};          // launch q was timed with the events k0 / k1 instead (no sort behind it)
     unsigned* h_chain = nullptr;  // pinned, one word per ring slot: longest ray chain + 1 of that launch (0 = not known yet)
     int frames_in_flight = 1;                 // vr_hint_frames_in_flight: frames the caller keeps in flight on different streams
     unsigned long long order_seq = 0;
@@ -102,6 +104,7 @@ struct vr_ctx {
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
     int cnt_blocks = 0;
+    bool exp_event_timing = false;             // experiment (VR_EXP_EVENT_TIMING=1): time every launch with events
     bool zskip = true;                         // per-step zero-opacity vote (VR_EXP_NO_ZSKIP=1 switches it off for A/B)
     size_t cnt_offset = 0;                     // ... and where in that buffer the records of its last frame start (u64 words)
     unsigned long long* h_counters = nullptr;  // pinned [3]
@@ -505,8 +508,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         P.block_counts = c->d_block_counts[cb];
         c->cnt_buf = cb;
-        // launch order: the most recent sort of a launch of the same shape that is three or four launches old (one or two
-        // more than the frames the caller says it keeps in flight, if that is more) -- a younger one may still be waiting
+        // launch order: the most recent sort of a launch of the same shape that is three or four launches old (two or three
+        // more than the frames the caller says it keeps in flight, if that is more: with short frames -- C2, 0.08 ms -- the
+        // sort of the launch that finished one frame time ago is itself only just finishing) -- a younger one may still be waiting
         // for its launch to finish (the sorts run on a side stream behind their launches; waiting for one would put a bubble
         // into this stream, and with four frames in flight it would chain this launch behind the one three before it), an
         // older one's buffer may be recycled under this launch; ordered behind it by its event (long complete by then)
@@ -517,7 +521,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const bool ordered = c->order_mode == 1 && !wtb && grid.x <= (unsigned)kOrderMaxBlocks && grid.x % 8u == 0;
         if (ordered) {
             const vr_ctx::OrderSlot* best = nullptr;
-            const unsigned long long age = (unsigned long long)(c->frames_in_flight + 1 > 3 ? c->frames_in_flight + 1 : 3);
+            const unsigned long long age = (unsigned long long)(c->frames_in_flight + 2 > 3 ? c->frames_in_flight + 2 : 3);
             for (const auto& o : c->order_ring)
                 if (o.valid && o.key == okey && o.seq + age + 1 >= c->order_seq && o.seq + age <= c->order_seq && (!best || o.seq > best->seq))
                     best = &o;
@@ -528,7 +532,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         const int slot = (int)(c->ring.head % kRing);
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
-        VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
+        // launches with a sort behind them are timed from their own records (order_blocks_kernel); events only otherwise
+        const bool time_with_events = !(ordered && c->h_span) || c->exp_event_timing;
+        c->ring_events[slot] = time_with_events;
+        if (c->h_span) c->h_span[slot] = 0;
+        if (time_with_events) VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
         {
             LaunchDesc L;
             L.variant = variant;
@@ -558,7 +566,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             else vr::launch_march(L, s, B);
         }
         VR_HIP(c, hipGetLastError());
-        VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
+        if (time_with_events) VR_HIP(c, hipEventRecord(c->ring.k1[slot], s));
         if (ordered) {
             vr_ctx::OrderSlot& o = c->order_ring[c->order_seq % kOrderRing];
             o.valid = false;
@@ -582,7 +590,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             vr_ctx::OrderSlot& o = c->order_ring[c->order_seq % kOrderRing];
             VR_HIP(c, hipStreamWaitEvent(c->order_stream, c->slot_done[cb], 0));
             hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, c->order_stream, c->d_block_counts[cb], (int)grid.x, o.buf,
-                               c->h_chain ? c->h_chain + (c->order_seq % kOrderRing) : (unsigned*)nullptr);
+                               c->h_chain ? c->h_chain + (c->order_seq % kOrderRing) : (unsigned*)nullptr,
+                               (c->h_span && !time_with_events) ? c->h_span + slot : (unsigned long long*)nullptr);
             VR_HIP(c, hipGetLastError());
             VR_HIP(c, hipEventRecord(o.sorted, c->order_stream));
             o.valid = true;
@@ -854,12 +863,17 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     // the sorts' barriers), and the full C3 frame gains nothing from a third frame in flight either way (tools/exp_tiles.py,
     // tools/exp_queues).
     if (!hip_ok(hipStreamCreateWithFlags(&c->order_stream, hipStreamNonBlocking), "hipStreamCreate")) return bail(VR_ERR_HIP);
+    if (hipHostMalloc((void**)&c->h_span, kRing * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess)
+        std::memset(c->h_span, 0, kRing * sizeof(unsigned long long));
+    else
+        c->h_span = nullptr;  // (every launch is then timed with events)
     if (hipHostMalloc((void**)&c->h_chain, kOrderRing * sizeof(unsigned), hipHostMallocDefault) == hipSuccess)
         std::memset(c->h_chain, 0, kOrderRing * sizeof(unsigned));
     else
         c->h_chain = nullptr;  // (the choice of lanes per ray then goes by the launch size alone)
     if (const char* e = getenv("VR_EXP_ORDER")) c->order_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_NO_ZSKIP")) c->zskip = atoi(e) == 0;
+    if (const char* e = getenv("VR_EXP_EVENT_TIMING")) c->exp_event_timing = atoi(e) != 0;
     if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 3 * sizeof(unsigned long long), hipHostMallocDefault),
                 "hipHostMalloc"))
@@ -919,6 +933,7 @@ void vr_destroy(vr_ctx* c)
     }
     if (c->order_stream) (void)hipStreamDestroy(c->order_stream);
     if (c->h_chain) (void)hipHostFree(c->h_chain);
+    if (c->h_span) (void)hipHostFree(c->h_span);
     for (int k = 0; k < c->n_flight; ++k) (void)hipStreamDestroy(c->flight[k]);
     if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
     if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);
@@ -1197,8 +1212,16 @@ int vr_kernel_times(vr_ctx* c, float* out_ms, int capacity)
     VR_HIP(c, hipSetDevice(c->device));
     long long have = c->ring.head < kRing ? c->ring.head : kRing;
     int n = (int)(have < capacity ? have : capacity);
+    bool synced = false;
     for (int i = 0; i < n; ++i) {
         int slot = (int)((c->ring.head - n + i) % kRing);
+        if (!c->ring_events[slot]) {  // from the launch's records, written by the sort that runs behind it
+            if (!synced) VR_HIP(c, hipStreamSynchronize(c->order_stream));
+            synced = true;
+            const unsigned long long ticks = *(volatile unsigned long long*)&c->h_span[slot];
+            out_ms[i] = ticks ? (float)((double)(ticks - 1) * 1.0e-5) : 0.0f;
+            continue;
+        }
         VR_HIP(c, hipEventSynchronize(c->ring.k1[slot]));
         VR_HIP(c, hipEventElapsedTime(&out_ms[i], c->ring.k0[slot], c->ring.k1[slot]));
     }
@@ -1208,6 +1231,9 @@ int vr_kernel_times(vr_ctx* c, float* out_ms, int capacity)
 int vr_reset_kernel_times(vr_ctx* c)
 {
     if (!c) return VR_ERR_INVALID_ARG;
+    // (sorts of earlier launches still report their launch's duration into the ring: let them finish first)
+    VR_HIP(c, hipSetDevice(c->device));
+    VR_HIP(c, hipStreamSynchronize(c->order_stream));
     c->ring.head = 0;
     return VR_OK;
 }

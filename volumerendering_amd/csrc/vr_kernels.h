@@ -1526,16 +1526,25 @@ __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks, unsi
 // 8 XCDs, so a block stays on the XCD its index maps to (what map_pixel's xcd_mode relies on) and every XCD runs its own
 // blocks longest-processing-time-first.  Eight counting sorts over 128 key buckets each (n_blocks % 8 == 0).
 constexpr int kOrderMaxBlocks = 192 * 1024;  // launches with more blocks keep the index order (C5, one wavefront per block: 130 560)
+// It also reports how long the launch took: last workgroup end - first workgroup start of the records it reads (100 MHz
+// ticks, to host-visible memory; vr_kernel_times).  Timing events around every launch cost the frame's stream 11 us.
 __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long long* __restrict__ in, int n_blocks,
-                                                            unsigned* __restrict__ order, unsigned* __restrict__ longest_chain)
+                                                            unsigned* __restrict__ order, unsigned* __restrict__ longest_chain,
+                                                            unsigned long long* __restrict__ span_ticks)
 {
     __shared__ unsigned hist[1024];  // [class 0..7][bucket 0..127]
     __shared__ unsigned base[1024];
     __shared__ unsigned chain_max;
+    __shared__ unsigned long long t_first, t_last;
     const int t = threadIdx.x;
     hist[t] = 0;
-    if (t == 0) chain_max = 0;
+    if (t == 0) {
+        chain_max = 0;
+        t_first = ~0ull;
+        t_last = 0ull;
+    }
     unsigned my_chain = 0;
+    unsigned long long my_first = ~0ull, my_last = 0ull;
     __syncthreads();
     // every record is read ONCE (a launch that recycles the record buffer under this kernel can then only change the
     // order, never make it something other than a permutation); bucket 0 = the longest chains (32 steps per bucket)
@@ -1544,6 +1553,9 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
         const int b = t + k * 1024;
         if (b < n_blocks) {
             const unsigned long long crit = in[(size_t)b * kBlockRecord + 5] >> 40;
+            const unsigned long long b0 = in[(size_t)b * kBlockRecord + 3], b1 = in[(size_t)b * kBlockRecord + 4];
+            my_first = b0 < my_first ? b0 : my_first;
+            my_last = b1 > my_last ? b1 : my_last;
             my_chain = crit > my_chain ? (unsigned)crit : my_chain;
             const unsigned q = (unsigned)(crit >> 5);
             bk[k] = (unsigned short)(((unsigned)b & 7u) * 128u + (127u - (q > 127u ? 127u : q)));
@@ -1572,6 +1584,14 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
         atomicMax(&chain_max, my_chain);
         __syncthreads();
         if (t == 0) *longest_chain = chain_max + 1u;
+    }
+    if (span_ticks) {
+        // (a launch of several frames: the first frame's records stand for all of them -- the frames' workgroups are
+        // interleaved, so its first start and last end are the launch's to within a few workgroup times)
+        atomicMin(&t_first, my_first);
+        atomicMax(&t_last, my_last);
+        __syncthreads();
+        if (t == 0) *span_ticks = t_last >= t_first ? t_last - t_first + 1ull : 1ull;  // (0 = not written yet)
     }
     // scatter with one cursor per (class, bucket): the i-th block of class x goes to position 8 * i + x
     for (int k = 0; k * 1024 < n_blocks; ++k) {
