@@ -266,6 +266,12 @@ int vr_last_timing(vr_ctx* ctx, float* kernel_ms, float* total_ms);
  * on their stream.  At most `capacity` (<= 256) values are written, the number written is returned (negative = error).
  * Waits for the launches concerned.  vr_reset_kernel_times() empties the ring.                                       */
 int vr_kernel_times(vr_ctx* ctx, float* out_ms, int capacity);
+
+/* How vr_kernel_times measures: VR_TIMING_RECORDS (default, as described above) or VR_TIMING_EVENTS -- a pair of HIP events
+ * around every march launch on the stream it is enqueued on, whatever the launch (what bench.py's roofline divides by).  */
+#define VR_TIMING_RECORDS 0
+#define VR_TIMING_EVENTS 1
+int vr_set_kernel_timing(vr_ctx* ctx, int mode);
 int vr_reset_kernel_times(vr_ctx* ctx);
 
 /* Viewport size and HIP device ordinal of a context (any pointer may be NULL). */

@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "vr_render_batch_async", "vr_render_tiles_batch_async", "vr_unpack_tiles_strided_async",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
     "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream", "vr_hint_frames_in_flight",
+    "vr_set_kernel_timing",
 ]
 
 
@@ -103,6 +104,7 @@ def load() -> C.CDLL:
     lib.vr_last_timing.argtypes = [vp, fp, fp]
     lib.vr_kernel_times.argtypes = [vp, vp, i32]
     lib.vr_reset_kernel_times.argtypes = [vp]
+    lib.vr_set_kernel_timing.argtypes = [vp, i32]
     lib.vr_frame_device_ptr.argtypes = [vp]
     lib.vr_frame_device_ptr.restype = vp
     lib.vr_last_covered_pixels.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -273,6 +275,10 @@ class Context:
 
     def reset_kernel_times(self):
         self._chk(self.lib.vr_reset_kernel_times(self.h))
+
+    def set_kernel_timing(self, events: bool):
+        """vr_kernel_times from HIP events around every launch (True) or from the launches' own records (False, the default)."""
+        self._chk(self.lib.vr_set_kernel_timing(self.h, 1 if events else 0))
 
     def covered_pixels(self) -> int:
         n = C.c_uint64(0)

@@ -104,7 +104,7 @@ struct vr_ctx {
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
     int cnt_blocks = 0;
-    bool exp_event_timing = false;             // experiment (VR_EXP_EVENT_TIMING=1): time every launch with events
+    bool event_timing = false;                 // vr_set_kernel_timing(VR_TIMING_EVENTS): time every launch with HIP events
     bool zskip = true;                         // per-step zero-opacity vote (VR_EXP_NO_ZSKIP=1 switches it off for A/B)
     size_t cnt_offset = 0;                     // ... and where in that buffer the records of its last frame start (u64 words)
     unsigned long long* h_counters = nullptr;  // pinned [3]
@@ -533,7 +533,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const int slot = (int)(c->ring.head % kRing);
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
         // launches with a sort behind them are timed from their own records (order_blocks_kernel); events only otherwise
-        const bool time_with_events = !(ordered && c->h_span) || c->exp_event_timing;
+        const bool time_with_events = !(ordered && c->h_span) || c->event_timing;
         c->ring_events[slot] = time_with_events;
         if (c->h_span) c->h_span[slot] = 0;
         if (time_with_events) VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
@@ -873,7 +873,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
         c->h_chain = nullptr;  // (the choice of lanes per ray then goes by the launch size alone)
     if (const char* e = getenv("VR_EXP_ORDER")) c->order_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_NO_ZSKIP")) c->zskip = atoi(e) == 0;
-    if (const char* e = getenv("VR_EXP_EVENT_TIMING")) c->exp_event_timing = atoi(e) != 0;
+    if (const char* e = getenv("VR_EXP_EVENT_TIMING")) c->event_timing = atoi(e) != 0;
     if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipHostMalloc((void**)&c->h_counters, 3 * sizeof(unsigned long long), hipHostMallocDefault),
                 "hipHostMalloc"))
@@ -1226,6 +1226,14 @@ int vr_kernel_times(vr_ctx* c, float* out_ms, int capacity)
         VR_HIP(c, hipEventElapsedTime(&out_ms[i], c->ring.k0[slot], c->ring.k1[slot]));
     }
     return n;
+}
+
+int vr_set_kernel_timing(vr_ctx* c, int mode)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (mode != VR_TIMING_RECORDS && mode != VR_TIMING_EVENTS) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_timing: bad mode");
+    c->event_timing = mode == VR_TIMING_EVENTS;
+    return VR_OK;
 }
 
 int vr_reset_kernel_times(vr_ctx* c)
