@@ -893,3 +893,37 @@ def test_kernel_times_from_the_launch_records_agree_with_events(ctx):
     for a, b in zip(kt, ev):
         # the event pair brackets the records' span: it adds the dispatch ramp and the events' own latency (some 10-30 us)
         assert a < b + 0.005 and b - a < 0.05, (kt, ev)
+
+
+@pytest.mark.parametrize("mode", ["fused", "otf"])
+def test_batched_launches_in_the_other_kernel_families(ctx, mode):
+    """The batch instantiations of the fused-arithmetic kernels (namespace vrf) and of the gradients-on-the-fly kernel are
+    separate code: each frame of a four-frame launch equals the single-frame render of the same mode bit for bit."""
+    W, H = 136, 100
+    ctx.resize(W, H)
+    vols, tfs = vt.scene(capi.LIGHT, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    us = _batch_uniforms(W, H, count, step)
+    others = [capi.Context(W, H, 0) for _ in range(4)]
+    try:
+        if mode == "fused":
+            ctx.set_arithmetic(capi.ARITH_FUSED)
+        else:
+            ctx.set_volume_layout(2)
+        refs = [vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs) for u in us]
+        for flavour in (0, 6, 11):
+            ctx.set_kernel_flavour(flavour)
+            ctx.render_batch_async(capi.LIGHT, [vt.to_capi_uniforms(u) for u in us], [o.frame_device_ptr() for o in others], ctx.stream(0))
+            assert ctx.counters()[0] == refs[3][2]
+            if mode == "otf" and flavour == 6:   # (the one-lane kernel; small default launches take the depth-parallel ones)
+                assert ctx.volume_layout(0) & 4   # the launch really derived its gradients from the density plane
+            ctx.resize(W, H)
+            for o, ref in zip(others, refs):
+                got, _, _ = o.download()
+                assert np.array_equal(vt.bits(got), vt.bits(ref[0])), (mode, flavour)
+    finally:
+        ctx.set_kernel_flavour(0)
+        ctx.set_arithmetic(capi.ARITH_SEPARATE)
+        ctx.set_volume_layout(0)
+        for o in others:
+            o.close()
