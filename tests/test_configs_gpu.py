@@ -115,6 +115,22 @@ def test_config_flavours_and_tile_partition_agree_at_full_size(workload):
                 total += cnt
             assert total == n_base
             assert np.array_equal(vt.bits(tiles.unpack(gathered, W, H, world)), vt.bits(base)), (workload, world)
+        assert_batched_frames_equal(app, variant, W, H, base, n_base)
+
+
+def assert_batched_frames_equal(app, variant, W, H, frame, n_samples):
+    """Three frames in one launch (vr_render_batch_async), the scene's own uniforms each: all equal the single-frame render."""
+    ctx = app.context()
+    others = [capi.Context(W, H, 0) for _ in range(3)]
+    try:
+        ctx.render_batch_async(variant, [app.uniforms()] * 3, [o.frame_device_ptr() for o in others], ctx.stream(0))
+        assert ctx.counters()[0] == n_samples
+        for o in others:
+            got, _, _ = o.download()
+            assert np.array_equal(vt.bits(got), vt.bits(frame))
+    finally:
+        for o in others:
+            o.close()
 
 
 def test_c5_16gib_volume_64bit_addressing_vs_oracle():
@@ -142,6 +158,7 @@ def test_c5_16gib_volume_64bit_addressing_vs_oracle():
             nt = ctx.tile_count(r, world)
             t, _ = ctx.download_tiles(nt)
             assert np.array_equal(vt.bits(t), vt.bits(tiles.pack(frag, r, world))), r
+        assert_batched_frames_equal(app, variant, W, H, frag, n_gpu)   # the 64-bit-offset batch kernel
         # thin TF (no ray terminates: the longest accumulation chains): every 16th 64x64 tile against the oracle
         wl.apply_tf(app, vname, "thin")
         app.OnUpdate()
