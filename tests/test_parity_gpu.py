@@ -871,6 +871,10 @@ def test_batch_arguments_are_checked(ctx):
     bad = vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=-1, step_size=step))
     with pytest.raises(capi.VrError):
         ctx.render_batch_async(capi.BASIC, [u, bad], [p, p])
+    moved = vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=count, step_size=step))
+    moved.model[12] = 0.25                                          # a model matrix other than the identity: as vr_set_uniforms
+    with pytest.raises(capi.VrError):
+        ctx.render_batch_async(capi.BASIC, [u, moved], [p, p])
 
 
 def test_kernel_times_from_the_launch_records_agree_with_events(ctx):

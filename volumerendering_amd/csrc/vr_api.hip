@@ -295,6 +295,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         for (int f = 0; f < n_frames; ++f) {
             if (!batch_out[f]) return fail(c, VR_ERR_INVALID_ARG, "vr_render: output buffer " + std::to_string(f) + " of the batch is NULL");
             if (batch_u[f].steps_count < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: negative steps_count");
+            if (!is_identity(batch_u[f].model))  // (as vr_set_uniforms)
+                return fail(c, VR_ERR_UNSUPPORTED, "vr_render: model matrix must be the identity (App/src/Application.cpp:489-492)");
         }
         out = (float4*)batch_out[0];
     } else {
