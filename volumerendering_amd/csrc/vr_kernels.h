@@ -683,10 +683,15 @@ __device__ __forceinline__ Src src_inshader(const MarchParams& P, f3 p, f3 w, fl
     o.a = t.opacity;
     return o;
 }
-__device__ __forceinline__ Src src_volume_mask(const MarchParams& P, f3 w, float4 mask, float rt, float4 ct)
+// (with_rt = false, wave-uniform: the caller knows that no ray of the packet can be masked -- mask is then 0 -- and has
+// not fetched the dose; its table look-up, whose result only a masked sample uses, is left out)
+__device__ __forceinline__ Src src_volume_mask(const MarchParams& P, f3 w, float4 mask, float rt, float4 ct, bool with_rt = true)
 {
     Src o;
-    TfSample trt = tf_lookup(P.tf[1], rt);
+    TfSample trt;
+    trt.rgb = mk3(0.0f, 0.0f, 0.0f);
+    trt.opacity = 0.0f;
+    if (with_rt) trt = tf_lookup(P.tf[1], rt);
     TfSample tct = tf_lookup(P.tf[0], ct.w);
     f3 N = normalize3(mk3(ct.x, ct.y, ct.z));
     f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(0.96f, 0.76f, 0.67f), mk3(1.0f, 1.0f, 1.0f), 1.5f, 0.5f);
@@ -792,6 +797,10 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     }
     return o;
 }
+template <bool FMED>
+__device__ __forceinline__ int brick_of(const MarchParams& P, f3 p);
+__device__ __forceinline__ float2 brick_record(const MarchParams& P, int bid);
+
 // True if the opacity table yields exactly 0 for density d: both texels of the look-up lie in the table's zero prefix
 // (the index is tf_fetch's own; a NaN or infinite density gives a NaN opacity and is not "zero").
 __device__ __forceinline__ bool opacity_is_zero(const MarchParams& P, float d)
@@ -869,12 +878,22 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
             // sample_src issues them, so a packet that does sample waits no longer than before; a packet in air saves the
             // table look-ups and the arithmetic (and, for the in-shader gradient, its six further density fetches)
             if constexpr (V == V_VOLUME_MASK) {
-                const float4 mask = tex3_rgba<OFF32>(P.vol[0], p);
-                const float rt = tex3_a<OFF32>(P.vol[1], p);
                 const float4 ct = tex3_rgba<OFF32>(P.vol[2], p);
+                // The mask enters the shader through one comparison (any of r, g, b > 0), and the dose only through the
+                // samples that pass it.  Where every mask voxel the sample's brick can touch is <= 0 -- the brick record the
+                // skipping test keeps anyway -- the interpolated channels are <= 0 too: for a packet all of whose rays are in
+                // such bricks (most of the body) neither the eight 16-byte mask corners nor the dose and its table are fetched.
+                float4 mask = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float rt = 0.0f;
+                const bool maybe_masked = !(brick_record(P, brick_of<OFF32>(P, p)).y <= 0.0f) || P.zskip_prefix < -1;
+                const bool any_masked = __ballot(maybe_masked) != 0;
+                if (any_masked) {
+                    mask = tex3_rgba<OFF32>(P.vol[0], p);
+                    rt = tex3_a<OFF32>(P.vol[1], p);
+                }
                 const bool inert = !(mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) && opacity_is_zero(P, ct.w);
                 if (__ballot(!inert) == 0) return;
-                const Src s = src_volume_mask(P, w, mask, rt, ct);
+                const Src s = src_volume_mask(P, w, mask, rt, ct, any_masked);
                 blend(s.rgb, s.a, dst);
             } else if constexpr (V == V_THREE_FILES) {
                 const float ct = tex3_a<OFF32>(P.vol[0], p);
