@@ -404,7 +404,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         P.bsy = (float)c->vol[sv].ny * kBrickInv;
         P.bsz = (float)c->vol[sv].nz * kBrickInv;
         P.tf_zero_prefix = c->tf_zero_prefix[0];
-        P.zskip_prefix = c->zskip ? P.tf_zero_prefix : -2;  // (-2: no vote, and the mask is always fetched)
+        P.zskip_prefix = c->zskip ? P.tf_zero_prefix : -2;  // (-2: no vote, and mask and dose are always fetched)
         P.bricks = c->vol_bricks[sv];
         P.use_rgb = 0;
         if (variant == VR_VARIANT_VOLUME_MASK) {

@@ -659,6 +659,18 @@ struct Src {
     f3 rgb;
     float a;
 };
+template <bool FMED>
+__device__ __forceinline__ int brick_of(const MarchParams& P, f3 p);
+__device__ __forceinline__ float2 brick_record(const MarchParams& P, int bid);
+
+// Three-volume composite: the mask enters the shader through one comparison (any of r, g, b > 0), and the dose only through
+// the samples that pass it.  Where every mask voxel the sample's brick can touch is <= 0 -- the brick record the skipping test
+// keeps anyway (kernels with skipping only: P.bricks) -- the interpolated channels are <= 0 too: for a packet all of whose
+// rays are in such bricks (most of the body) neither the eight 16-byte mask corners nor the dose are fetched (mask = 0 fails
+// the comparison like the real value; *any_masked = false tells src_volume_mask to leave the dose's table out as well).
+template <bool OFF32>
+__device__ __forceinline__ void fetch_mask_and_dose(const MarchParams& P, f3 p, float4& mask, float& rt, bool& any_masked);
+
 // The arithmetic of three shaders behind their fetches (sample_src fetches and calls these; sample_and_blend puts its vote
 // between the two).
 template <bool OFF32>
@@ -715,6 +727,20 @@ __device__ __forceinline__ Src src_three_files(const MarchParams& P, float ct, f
     return o;
 }
 
+template <bool OFF32>
+__device__ __forceinline__ void fetch_mask_and_dose(const MarchParams& P, f3 p, float4& mask, float& rt, bool& any_masked)
+{
+    mask = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    rt = 0.0f;
+    any_masked = true;
+    if (P.bricks != nullptr && P.use_rgb && P.zskip_prefix >= -1)  // (wave-uniform)
+        any_masked = __ballot(!(brick_record(P, brick_of<OFF32>(P, p)).y <= 0.0f)) != 0;
+    if (any_masked) {
+        mask = tex3_rgba<OFF32>(P.vol[0], p);
+        rt = tex3_a<OFF32>(P.vol[1], p);
+    }
+}
+
 // (start = the ray's first position and dst_a = the opacity accumulated so far are read by the illustrative shader only,
 // ss = the ray's step size after the variable-step override by the in-shader gradient only)
 template <int V, bool OFF32, bool OTF = false>
@@ -739,10 +765,12 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     } else if constexpr (V == V_LIGHT_INSHADER) {
         o = src_inshader<OFF32>(P, p, w, ss, tex3_a<OFF32>(P.vol[0], p));
     } else if constexpr (V == V_VOLUME_MASK) {
-        const float4 mask = tex3_rgba<OFF32>(P.vol[0], p);
-        const float rt = tex3_a<OFF32>(P.vol[1], p);
         const float4 ct = tex3_rgba<OFF32>(P.vol[2], p);
-        o = src_volume_mask(P, w, mask, rt, ct);
+        float4 mask;
+        float rt;
+        bool any_masked;
+        fetch_mask_and_dose<OFF32>(P, p, mask, rt, any_masked);
+        o = src_volume_mask(P, w, mask, rt, ct, any_masked);
     } else if constexpr (V == V_THREE_FILES) {
         const float ct = tex3_a<OFF32>(P.vol[0], p);
         const float rt = tex3_a<OFF32>(P.vol[1], p);
@@ -797,10 +825,6 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     }
     return o;
 }
-template <bool FMED>
-__device__ __forceinline__ int brick_of(const MarchParams& P, f3 p);
-__device__ __forceinline__ float2 brick_record(const MarchParams& P, int bid);
-
 // True if the opacity table yields exactly 0 for density d: both texels of the look-up lie in the table's zero prefix
 // (the index is tf_fetch's own; a NaN or infinite density gives a NaN opacity and is not "zero").
 __device__ __forceinline__ bool opacity_is_zero(const MarchParams& P, float d)
@@ -879,18 +903,10 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
             // table look-ups and the arithmetic (and, for the in-shader gradient, its six further density fetches)
             if constexpr (V == V_VOLUME_MASK) {
                 const float4 ct = tex3_rgba<OFF32>(P.vol[2], p);
-                // The mask enters the shader through one comparison (any of r, g, b > 0), and the dose only through the
-                // samples that pass it.  Where every mask voxel the sample's brick can touch is <= 0 -- the brick record the
-                // skipping test keeps anyway -- the interpolated channels are <= 0 too: for a packet all of whose rays are in
-                // such bricks (most of the body) neither the eight 16-byte mask corners nor the dose and its table are fetched.
-                float4 mask = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                float rt = 0.0f;
-                const bool maybe_masked = !(brick_record(P, brick_of<OFF32>(P, p)).y <= 0.0f) || P.zskip_prefix < -1;
-                const bool any_masked = __ballot(maybe_masked) != 0;
-                if (any_masked) {
-                    mask = tex3_rgba<OFF32>(P.vol[0], p);
-                    rt = tex3_a<OFF32>(P.vol[1], p);
-                }
+                float4 mask;
+                float rt;
+                bool any_masked;
+                fetch_mask_and_dose<OFF32>(P, p, mask, rt, any_masked);
                 const bool inert = !(mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) && opacity_is_zero(P, ct.w);
                 if (__ballot(!inert) == 0) return;
                 const Src s = src_volume_mask(P, w, mask, rt, ct, any_masked);
