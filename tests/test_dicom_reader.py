@@ -150,3 +150,59 @@ def test_deeply_nested_items_and_missing_meta_group_are_rejected(tmp_path):
     g.write_bytes(b"\0" * 128 + b"DICM" + dw.element(0x00080060, "CS", "CT", True))
     with pytest.raises(IOError, match="no file meta information"):
         host.VolumeFile.from_dicom(str(g))
+
+
+def test_hand_assembled_part10_file_byte_for_byte(tmp_path):
+    """A DICOM Part 10 file spelled out byte by byte from the standard's encoding rules (PS3.10 section 7.1: 128-byte preamble +
+    "DICM"; PS3.5 section 7.1.2: explicit-VR little-endian data elements -- tag, two-letter VR, then a 16-bit length, or for
+    OB / OW / SQ / UN two reserved bytes and a 32-bit length; section 7.5: sequence items FFFE,E000 and delimiters
+    FFFE,E00D / FFFE,E0DD with undefined length FFFFFFFF; section 6.2: UI padded with NUL, the text VRs with a space).  It shares
+    nothing with tests/dicom_writer.py, so the reader is not only checked against this repository's own writer."""
+    h = bytes.fromhex
+    meta = (h("0200 0100 4f42 0000 02000000 0001")                              # (0002,0001) OB  FileMetaInformationVersion 00\\01
+            + h("0200 1000 5549 1400") + b"1.2.840.10008.1.2.1\x00")             # (0002,0010) UI  Explicit VR Little Endian, NUL pad
+    blob = (b"\x00" * 128 + b"DICM"
+            + h("0200 0000 554c 0400") + len(meta).to_bytes(4, "little") + meta  # (0002,0000) UL  group length
+            + h("0800 6000 4353 0200") + b"CT"                                   # (0008,0060) CS  Modality
+            # (0008,1140) SQ ReferencedImageSequence, undefined length, one item of undefined length holding an SH and a
+            # private LO: the reader has to step over it without knowing the tags
+            + h("0800 4011 5351 0000 ffffffff")
+            + h("feff 00e0 ffffffff")
+            + h("0800 0001 5348 0400") + b"CODE"
+            + h("0900 1000 4c4f 0800") + b"PRIVATE "
+            + h("feff 0de0 00000000")
+            + h("feff dde0 00000000")
+            + h("1800 5000 4453 0400") + b"2.5 "                                 # (0018,0050) DS  SliceThickness, space pad
+            + h("2000 1300 4953 0200") + b"7 "                                   # (0020,0013) IS  InstanceNumber
+            + h("2000 3200 4453 0e00") + b"1.5\\-2.0\\3.25 "                       # (0020,0032) DS  ImagePositionPatient (13 + pad)
+            + h("2000 3700 4453 0c00") + b"1\\0\\0\\0\\1\\0 "                        # (0020,0037) DS  ImageOrientationPatient
+            + h("2000 5200 5549 0800") + b"1.2.3.4\x00"                          # (0020,0052) UI  FrameOfReferenceUID
+            + h("2800 1000 5553 0200 0300")                                      # (0028,0010) US  Rows = 3
+            + h("2800 1100 5553 0200 0200")                                      # (0028,0011) US  Columns = 2
+            + h("2800 3000 4453 0800") + b"0.5\\0.25"                             # (0028,0030) DS  PixelSpacing row \\ column
+            + h("2800 0001 5553 0200 1000")                                      # (0028,0100) US  BitsAllocated = 16
+            + h("2800 0101 5553 0200 0c00")                                      # (0028,0101) US  BitsStored = 12
+            + h("2800 0701 5553 0200 a00f")                                      # (0028,0107) US  LargestImagePixelValue = 4000
+            + h("e07f 1000 4f57 0000 0c000000")                                  # (7FE0,0010) OW  PixelData, 12 bytes
+            + h("0100 0200 0300 0400 0500 e803"))                                # 1 2 3 4 5 1000, little endian
+    f = tmp_path / "standard.dcm"
+    f.write_bytes(blob)
+    vf = host.VolumeFile.from_dicom(str(f))
+    p = vf.dicom_params()
+    assert vf.GetSize() == (3, 2, 1)             # the reader maps X <- Rows, Y <- Columns (DicomReader.cpp:181-182)
+    assert p["Modality"] == "CT" and p["BitsAllocated"] == 16 and p["SliceThickness"] == 2.5
+    assert p["PixelSpacing"] == [0.5, 0.25] and p["FrameOfReference"] == "1.2.3.4"
+    assert vf.GetMaxNumber() == 4000
+    assert vf.data()[..., 0].ravel().tolist() == [1.0, 2.0, 3.0, 4.0, 5.0, 1000.0]
+    # the same data set in the DEFAULT transfer syntax (implicit VR little endian, PS3.5 annex A.1: tag + 32-bit length, no VR)
+    def implicit(tag_hex, value):
+        return h(tag_hex) + len(value).to_bytes(4, "little") + value
+    meta_i = h("0200 0100 4f42 0000 02000000 0001") + h("0200 1000 5549 1200") + b"1.2.840.10008.1.2\x00"
+    blob_i = (b"\x00" * 128 + b"DICM" + h("0200 0000 554c 0400") + len(meta_i).to_bytes(4, "little") + meta_i
+              + implicit("0800 6000", b"CT") + implicit("2000 1300", b"7 ") + implicit("2800 1000", h("0300"))
+              + implicit("2800 1100", h("0200")) + implicit("2800 0001", h("1000")) + implicit("2800 0101", h("0c00"))
+              + implicit("e07f 1000", h("0100 0200 0300 0400 0500 e803")))
+    g = tmp_path / "implicit.dcm"
+    g.write_bytes(blob_i)
+    vi = host.VolumeFile.from_dicom(str(g))
+    assert vi.GetSize() == (3, 2, 1) and vi.data()[..., 0].ravel().tolist() == [1.0, 2.0, 3.0, 4.0, 5.0, 1000.0]
