@@ -346,6 +346,8 @@ def main():
             mg.frames_async(variant, [app.uniforms()] * fpl)
             mg.wait()
 
+    batch_written = set()  # (buffer set, frame of the launch) the batched launches have written so far
+
     def run_frames(n_frames, nbuf, fpl=1):
         if not multi:
             if fpl > 1 and nbuf > 1:  # one launch carries fpl frames (same camera in this bench; each frame marched in full)
@@ -353,6 +355,7 @@ def main():
                 while k < n_frames:
                     n = min(fpl, n_frames - k)
                     ctx.render_batch_async(variant, [u] * n, [t.data_ptr() for t in batch_frames[launch % nbuf][:n]], streams[launch % nbuf])
+                    batch_written.update((launch % nbuf, j) for j in range(n))
                     k += n
                     launch += 1
                 return
@@ -426,7 +429,7 @@ def main():
     # ... and the throughput leg proper: two launches in flight, fpl frames per launch
     dt_over, kt_over = timed_leg(nbuf_over, args.warmup, args.steps, fpl=fpl)
     if batch_frames:  # the frames of the batched launches must equal the one-at-a-time leg's frame bit for bit
-        if not all(bool(torch.equal(t.view(torch.int32), frames[0].view(torch.int32))) for bs_ in batch_frames for t in bs_):
+        if not all(bool(torch.equal(batch_frames[b][j].view(torch.int32), frames[0].view(torch.int32))) for b, j in sorted(batch_written)):
             raise SystemExit("bench.py: a frame of a batched launch differs from the single-frame render")
 
     # composited samples / covered pixels / samples whose voxels were fetched, for this rank's share of the frame
