@@ -343,7 +343,8 @@ def main():
 
     if mg is not None and fpl > 1:  # size the loop's buffer sets for fpl frames per launch outside every timed region
         with stdout_to_stderr():
-            mg.frames_async(variant, [app.uniforms()] * fpl)
+            for _ in range(max_flight):  # (every buffer set: the final comparison reads all of their frames)
+                mg.frames_async(variant, [app.uniforms()] * fpl)
             mg.wait()
 
     batch_written = set()  # (buffer set, frame of the launch) the batched launches have written so far
