@@ -115,11 +115,26 @@ def pmc_child(args):
             app.context().set_kernel_flavour(args.flavour)
         app.context().set_volume_layout(args.layout)
         app.context().set_arithmetic(1 if args.arith == "fused" else 0)
+        if args.frames_per_launch > 1:
+            # launches of several frames, one launch at a time, into the frame buffers of helper contexts (no torch here)
+            from volumerendering_amd import capi
+            ctx = app.context()
+            n = min(4, args.frames_per_launch)
+            others = [capi.Context(W, H, 0) for _ in range(n)]
+            try:
+                u = app.uniforms()
+                for _ in range(5):
+                    ctx.render_batch_async(capi.VARIANT_NAMES.index(vname), [u] * n, [o.frame_device_ptr() for o in others])  # the context's own stream
+                    ctx.counters()  # waits for the launch
+            finally:
+                for o in others:
+                    o.close()
+            return
         for _ in range(4):
             app.OnRender()
 
 
-def live_pmc(args, passes=PMC_PASSES, timeout_s=150):
+def live_pmc(args, passes=PMC_PASSES, timeout_s=150, frames_per_launch=0):
     """Runs rocprofv3 --pmc passes (one counter group per run, with --kernel-trace only) on `bench.py --pmc-child` and
     returns {counter: mean per march-kernel launch}.  Empty dict when rocprofv3 is unavailable or a pass fails."""
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -135,6 +150,8 @@ def live_pmc(args, passes=PMC_PASSES, timeout_s=150):
         cmd = [prof, "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload, "--tf", args.tf, "--air", args.air,
                "--flavour", str(args.flavour), "--vol-n", str(args.vol_n), "--layout", str(args.layout), "--arith", args.arith]
+        if frames_per_launch > 1:
+            cmd += ["--frames-per-launch", str(frames_per_launch)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
         except Exception as e:  # noqa: BLE001
@@ -570,6 +587,22 @@ def main():
             "note": "bytes the lanes receive from L1 (corner voxels + transfer-function texels of every fetched sample) against the "
                     "64 B/clk/CU return path of the vector memory pipeline at the measured clock; TA_BUSY_avr = busy cycles of the "
                     "texture addressers per launch"}
+        # the same two units measured on launches of `fpl` frames (one launch at a time: counters of overlapping dispatches
+        # cannot be told apart), instead of scaled from the one-frame launches
+        if fpl > 1 and not args.no_live_pmc:
+            bp, bnote = live_pmc(args, [["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"], ["GRBM_GUI_ACTIVE", "TA_BUSY_avr"]], frames_per_launch=fpl)
+            if "SQ_ACTIVE_INST_VALU" in bp and "GRBM_GUI_ACTIVE" in bp:
+                bcyc = bp["GRBM_GUI_ACTIVE"] / 8.0
+                roofline["batched_launch_measured"] = {
+                    "frames_per_launch": fpl, "launches_in_flight": 1,
+                    "valu_busy_frac": round(bp["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * bcyc), 4),
+                    "ta_busy_frac": round(bp["TA_BUSY_avr"] / bcyc, 4) if "TA_BUSY_avr" in bp else None,
+                    "valu_insts_per_frame": round(bp.get("SQ_INSTS_VALU", 0.0) / fpl),
+                    "profiled_ms_per_frame": round(bp["_profiled_march_ms"] / fpl, 4) if "_profiled_march_ms" in bp else None,
+                    "note": "rocprofv3 --pmc passes on launches that carry several frames, one launch at a time; the throughput "
+                            "leg keeps two such launches in flight"}
+            elif bnote:
+                log(f"[bench] batched counter passes: {bnote}")
         fr = {"hbm": roofline["frac_overlapped"] or 0, "valu-issue": roofline["valu"]["busy_frac_overlapped"] or 0,
               "l1-return-path": roofline["l1"]["ta_busy_frac_overlapped"] or roofline["l1"]["frac_overlapped"] or 0}
         roofline["limiter"] = max(fr, key=fr.get) + " (throughput leg); longest-ray tail on top of it in the serial leg"
