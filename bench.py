@@ -368,7 +368,7 @@ def main():
 
     def run_frames(n_frames, nbuf, fpl=1):
         if not multi:
-            if fpl > 1 and nbuf > 1:  # one launch carries fpl frames (same camera in this bench; each frame marched in full)
+            if fpl > 1:  # one launch carries fpl frames (same camera in this bench; each frame marched in full)
                 u, k, launch = app.uniforms(), 0, 0
                 while k < n_frames:
                     n = min(fpl, n_frames - k)
@@ -442,8 +442,8 @@ def main():
     _, kt_events = timed_leg(1, 3, 20)
     ctx.set_kernel_timing(False)
     nbuf_over = max_flight if mg is not None else min(args.in_flight, max_flight)
-    if nbuf_over == 1:
-        fpl = 1  # (--in-flight 1: one frame at a time in this leg too -- launches of several frames are its throughput form)
+    if nbuf_over == 1 and args.frames_per_launch <= 0:
+        fpl = 1  # (--in-flight 1: one frame at a time in this leg too, unless --frames-per-launch asks for batched launches)
     # two launches in flight, one frame each (round 1's and early round 2's throughput leg; kept for comparison) ...
     dt_pipe, kt_pipe = timed_leg(nbuf_over, args.warmup, args.steps) if fpl > 1 else (None, None)
     # ... and the throughput leg proper: two launches in flight, fpl frames per launch
