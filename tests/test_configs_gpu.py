@@ -96,7 +96,7 @@ def test_config_flavours_and_tile_partition_agree_at_full_size(workload):
         ctx = app.context()
         ctx.set_kernel_flavour(1)
         base, n_base, cov_base, _ = gpu_frame(app)
-        for fl in (0, 6, 11, 10):
+        for fl in (0, 6, 11, 10, 12):
             ctx.set_kernel_flavour(fl)
             frag, n_f, cov_f, _ = gpu_frame(app)
             assert np.array_equal(vt.bits(frag), vt.bits(base)), (workload, fl)
@@ -145,7 +145,7 @@ def test_c5_16gib_volume_64bit_addressing_vs_oracle():
         assert (n_gpu, cov_gpu) == (n_ref, cov_ref)
         del ref
         # no-skipping kernel and the depth-parallel kernels: same bits, same counts
-        for fl in (1, 11):
+        for fl in (1, 11, 12):
             ctx.set_kernel_flavour(fl)
             f2, n2, cov2, _ = gpu_frame(app)
             assert np.array_equal(vt.bits(f2), vt.bits(frag)), fl

@@ -233,7 +233,7 @@ def test_skipping_with_hostile_values(ctx):
     tf = zero_prefix_tf(32, 3)
     for variant in (capi.BASIC, capi.LIGHT, capi.LIGHT_INSHADER):
         ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
-        for flavour in (0, 1, 5, 6, 8, 9, 11):  # every loop form and lanes-per-ray layout
+        for flavour in (0, 1, 5, 6, 8, 9, 11, 12, 13):  # every loop form and lanes-per-ray layout
             ctx.set_kernel_flavour(flavour)
             frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
             assert same(frag, ref) and ns == n_ref, (variant, flavour)
@@ -248,7 +248,7 @@ def test_skipping_with_hostile_values(ctx):
         for variant in (capi.BASIC, capi.LIGHT):
             ref, n_ref, _ = ob.render(variant, u, [lone], [tf], W, H, nthreads=8)
             assert np.isnan(ref).any()
-            for flavour in (0, 6, 11):
+            for flavour in (0, 6, 11, 12, 13):
                 ctx.set_kernel_flavour(flavour)
                 frag, _, ns = vt.gpu_render(ctx, variant, u, [lone], [tf])
                 assert same(frag, ref) and ns == n_ref, (bad, where, variant, flavour)
@@ -367,7 +367,7 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
                 assert ctx.counters()[2] < 0.5 * ns
 
 
-@pytest.mark.parametrize("flavour", [4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("flavour", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_exact_leaping_flavour(ctx, flavour):
     """Every way of getting through empty space and every lanes-per-ray layout must reproduce the step-by-step
     accumulation bit for bit (frames AND sample counts): 5 single steps, 6 wave-uniform runs of plain additions,
@@ -392,7 +392,7 @@ def test_exact_leaping_flavour(ctx, flavour):
                 kw.update(extra)
                 u = hr.make_uniforms(W, H, **kw)
                 for variant in (capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.LIGHT_INSHADER):
-                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6):
+                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6, 12, 13):
                         continue  # one-lane kernel only: the other flavours resolve to 6
                     vols = [v] if variant != capi.THREE_FILES else [v, vt.dose_volume()]
                     tfs = [tf] if variant != capi.THREE_FILES else [tf, vt.scene(capi.THREE_FILES, n=8)[1][1]]
@@ -405,7 +405,7 @@ def test_exact_leaping_flavour(ctx, flavour):
         ctx.set_kernel_flavour(0)
 
 
-@pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("variant", range(8))
 def test_every_variant_every_layout(ctx, variant, flavour):
     """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
@@ -433,7 +433,7 @@ def test_default_layout_follows_launch_size(ctx):
     ctx.resize(W, H)
     try:
         frames = []
-        for fl in (0, 6, 7, 8, 10, 11):
+        for fl in (0, 6, 7, 8, 10, 11, 12, 13):
             ctx.set_kernel_flavour(fl)
             frag, _, n = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
             frames.append((vt.bits(frag), n))
@@ -672,7 +672,7 @@ def test_fused_every_variant_every_loop_form(fused, variant):
     W, H = 70, 45
     vols, tfs = vt.scene(variant, n=24)
     step, count = hr.stepping_params(24, 24, 24)
-    for fl in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11):
+    for fl in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
         fused.set_kernel_flavour(fl)
         for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
                    dict(distance=0.7, yaw=1.0)):
@@ -692,7 +692,7 @@ def test_fused_empty_space_skipping_is_exact(fused, variant, zeros):
     for cam in (dict(yaw=0.9, pitch=-0.3), dict(yaw=-2.1, pitch=0.6, distance=0.85)):
         u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam)
         outs = []
-        for fl in (0, 1, 5, 11):
+        for fl in (0, 1, 5, 11, 12, 13):
             fused.set_kernel_flavour(fl)
             frag, n_s = check(fused, variant, u, vols, tfs, W, H)
             outs.append((vt.bits(frag), n_s))
@@ -931,3 +931,65 @@ def test_batched_launches_in_the_other_kernel_families(ctx, mode):
         ctx.set_volume_layout(0)
         for o in others:
             o.close()
+
+
+# ---- persistent wavefronts (flavour 12, csrc/vr_pw.h) ---------------------------------------------------------------------
+def test_persistent_wavefronts_queue_and_lds_table(ctx):
+    """The persistent-wavefront kernel: packets come from a queue with eight heads, TF slot 0 is read from LDS.  Launch after
+    launch on one context (the heads must be zero again every time: cleared by the sort behind an ordered launch, by a
+    memset otherwise), more packets than wavefronts (1920x1080: 32 640 packets, 4 096 wavefronts) and fewer (24x16), tables of
+    4096 entries (64 KiB + 32 B of LDS: beyond the 64 KiB default limit of dynamic LDS), tables of two different
+    resolutions (the LDS form needs one index for both: falls back to L1), every launch bit-equal to the oracle."""
+    step, count = hr.stepping_params(24, 24, 24)
+    try:
+      for pw in (12, 13):  # 13: the same with the next step's corner loads software-pipelined
+        ctx.set_kernel_flavour(pw)
+        for W, H, kw in ((24, 16, dict()), (200, 120, dict(yaw=1.1, pitch=-0.2)), (96, 80, dict(distance=0.8))):
+            for res_o, res_c in ((4096, 4096), (256, 256), (64, 128), (8190, 8190), (8191, 8191)):
+                vols, _ = vt.scene(capi.LIGHT, n=24)
+                tf = (hr.default_opacity_tf(res_o), hr.default_color_tf(res_c))
+                u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **kw)
+                for variant in (capi.LIGHT, capi.BASIC):
+                    for _ in range(3):  # the same queue slot comes round again after eight launches
+                        check(ctx, variant, u, vols, [tf], W, H)
+                    assert ctx.last_kernel_flavour() == pw
+        # a 1080p frame: every wavefront takes several packets; ten launches in a row, two of them without a launch order
+        W, H = 1920, 1080
+        vols, tfs = vt.scene(capi.LIGHT, n=24)
+        u = hr.make_uniforms(W, H, steps_count=count, step_size=step, distance=0.9)
+        ctx.resize(W, H)
+        ctx.set_kernel_flavour(6)
+        ref, _, n_ref = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+        ctx.set_kernel_flavour(pw)
+        for k in range(10):
+            frag, _, n = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+            assert n == n_ref and np.array_equal(vt.bits(frag), vt.bits(ref)), k
+    finally:
+        ctx.set_kernel_flavour(0)
+        ctx.resize(96, 80)
+
+
+def test_persistent_wavefronts_block_records(ctx):
+    """The per-packet records of a persistent launch are indexed by logical block like march_kernel's: same sums, and every
+    record's counts equal those of the one-packet-per-workgroup kernel."""
+    W, H = 320, 200
+    vols, tfs = vt.scene(capi.LIGHT, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
+    ctx.resize(W, H)
+    try:
+        recs = []
+        for fl in (6, 12, 13):
+            ctx.set_kernel_flavour(fl)
+            for _ in range(5):  # (from the fourth launch on the blocks are taken longest first)
+                vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+            recs.append(ctx.block_trace().astype(np.uint64))
+        a = recs[0]
+        for b in recs[1:]:
+            assert a.shape == b.shape and a.shape[0] > 0
+            assert np.array_equal(a[:, :3], b[:, :3])                     # composited, covered, fetched per logical block
+            assert np.array_equal(a[:, 5] >> 40, b[:, 5] >> 40)           # longest ray chain per block
+            assert (b[:, 4] >= b[:, 3]).all()
+    finally:
+        ctx.set_kernel_flavour(0)
+        ctx.resize(96, 80)

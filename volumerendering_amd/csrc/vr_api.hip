@@ -80,6 +80,8 @@ struct vr_ctx {
     size_t block_counts_cap[kInFlight] = {};   // in blocks
     hipEvent_t slot_done[kInFlight] = {};      // recorded behind the launch that last used the slot (any stream)
     bool slot_used[kInFlight] = {};
+    unsigned* d_pw_heads = nullptr;            // queue heads of the persistent-wavefront kernel: kInFlight x 8 heads, 256 B apart
+    bool pw_heads_dirty[kInFlight] = {};       // the slot's last persistent launch had no sort behind it to clear its heads
     // Longest-first launch order (MarchParams::order): behind every march launch one small kernel sorts that launch's
     // blocks by their longest ray chain; a later launch of the same shape takes its blocks in that order.
     struct OrderSlot {
@@ -100,7 +102,6 @@ struct vr_ctx {
     int n_flight = 0;
     hipStream_t order_stream = nullptr;  // the sorts run here, behind their launch's event: never on a frame's critical path
     int order_mode = 1;  // 0 = launch the blocks in index order (VR_EXP_ORDER=0)
-    unsigned launch_seq = 0;
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
     int cnt_blocks = 0;
@@ -120,6 +121,7 @@ struct vr_ctx {
     int last_flavour = 0;     // the flavour the last launch resolved to
     bool last_otf = false;    // ... and whether it derived the gradients from the density plane
     int xcd_mode = 1;         // deal a tile's workgroups over the XCDs (VR_EXP_XCD=0: one XCD per tile)
+    bool pw_ltf = true;       // persistent wavefronts keep TF slot 0 in LDS (VR_EXP_PW_LTF=0: from L1, for A/B)
     std::string err;
 };
 
@@ -381,10 +383,12 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const bool short_chains = chain != 0 && chain - 1 < 128;
         fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
     }
+    // persistent wavefronts (12; vr_pw.h) exist for launches of one frame
+    if ((fl == 12 || fl == 13) && n_frames != 1) fl = 6;
     // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
     if (variant == VR_VARIANT_ILLUSTRATIVE && (fl == 7 || fl == 8 || fl == 10 || fl == 11)) fl = 6;
     // the in-shader gradient variant (seven density fetches per sample) exists as the one-lane kernel only
-    if (variant == VR_VARIANT_LIGHT_INSHADER && fl != 1 && fl != 4 && fl != 5) fl = 6;
+    if (variant == VR_VARIANT_LIGHT_INSHADER && fl != 1 && fl != 4 && fl != 5 && fl != 12 && fl != 13) fl = 6;
     c->last_flavour = fl;
     bool can_skip = skip_variant && fl != 1 && fl != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0];
@@ -486,12 +490,15 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // one wavefront per workgroup (launch order at wavefront granularity) -- except for the depth-parallel kernels on
         // large launches, where 4x the workgroups cost more at dispatch than the finer order gains (C2: 32 768 workgroups of
         // a 0.12 ms frame)
-        int wpb = wtb ? 4 : c->waves_per_block;
+        const bool pw = fl == 12 || fl == 13;
+        int wpb = wtb ? 4 : (pw ? 1 : c->waves_per_block);
         if (dp && P.n_tiles * (dp == 4 ? 256 : 128) > 16384) wpb = 4;
         dim3 block((unsigned)(64 * wpb));
         dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 256 : 128) / wpb : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel / map_pixel_dp
         if (n_frames > 1 && grid.x % 8u != 0) return fail(c, VR_ERR_INVALID_ARG, "vr_render: launch shape cannot carry several frames");
-        const int cb = (int)(c->launch_seq++ % (unsigned)kInFlight);
+        // (record slot and order slot are both derived from order_seq, which advances only once a launch has really been
+        // enqueued: a failed enqueue cannot shift one against the other)
+        const int cb = (int)(c->order_seq % (unsigned long long)kInFlight);
         // the slot's previous launch (kInFlight launches ago, possibly on another stream) must have finished before its
         // record buffer is written again or re-allocated: this is what bounds the launches in flight to kInFlight
         if (c->slot_used[cb]) VR_HIP(c, hipEventSynchronize(c->slot_done[cb]));
@@ -548,6 +555,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.dp_pipe = dp_pipe;
             L.wtb = wtb;
             L.otf = otf;
+            L.pw = false;
+            L.pw_ltf = false;
+            L.pw_pipe = false;
+            L.lds_bytes = 0;
+            L.queue = PwQueue{nullptr, 0u};
             L.grid = grid;
             L.block = block;
             // frame f of the launch: every n_frames-th group of 8 workgroups (MarchBatch), its own uniforms, output and
@@ -564,6 +576,23 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             }
             B.n_frames = (unsigned)n_frames;
             L.grid = dim3(grid.x * (unsigned)n_frames);
+                if (pw) {
+                // persistent wavefronts: `grid` stays the number of LOGICAL blocks (records, launch order); the launch itself is one
+                // workgroup of 16 wavefronts per CU (fewer when there are fewer packets), TF slot 0 in LDS when its two tables
+                // have one resolution and fit beside nothing else (R <= 8190: 128 KiB)
+                const unsigned per_wg = 1024u / 64u;
+                const unsigned wgs = (grid.x + per_wg - 1u) / per_wg;
+                L.pw = true;
+                L.pw_pipe = fl == 13;
+                L.pw_ltf = c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c && c->tf[0].res_o + 2 <= 8192;
+                L.lds_bytes = L.pw_ltf ? (unsigned)(c->tf[0].res_o + 2) * 16u : 0u;
+                L.queue.heads = c->d_pw_heads + (size_t)cb * 8 * 64;
+                L.queue.n_items = grid.x;
+                L.grid = dim3(wgs < (unsigned)c->n_cus ? wgs : (unsigned)c->n_cus);
+                L.block = dim3(1024);
+                if (c->pw_heads_dirty[cb]) VR_HIP(c, hipMemsetAsync(L.queue.heads, 0, 8 * 64 * sizeof(unsigned), s));
+                c->pw_heads_dirty[cb] = !ordered;  // (an ordered launch's sort clears them behind it)
+            }
             if (c->arith == VR_ARITH_FUSED) vrf::launch_march(L, s, B);
             else vr::launch_march(L, s, B);
         }
@@ -593,7 +622,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             VR_HIP(c, hipStreamWaitEvent(c->order_stream, c->slot_done[cb], 0));
             hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, c->order_stream, c->d_block_counts[cb], (int)grid.x, o.buf,
                                c->h_chain ? c->h_chain + (c->order_seq % kOrderRing) : (unsigned*)nullptr,
-                               (c->h_span && !time_with_events) ? c->h_span + slot : (unsigned long long*)nullptr);
+                               (c->h_span && !time_with_events) ? c->h_span + slot : (unsigned long long*)nullptr,
+                               pw ? c->d_pw_heads + (size_t)cb * 8 * 64 : (unsigned*)nullptr);
             VR_HIP(c, hipGetLastError());
             VR_HIP(c, hipEventRecord(o.sorted, c->order_stream));
             o.valid = true;
@@ -846,6 +876,9 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_FLAVOUR")) c->default_flavour = atoi(e);
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
+    if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
+    if (!hip_ok(hipMalloc(&c->d_pw_heads, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMalloc(queue heads)")) return bail(VR_ERR_HIP);
+    if (!hip_ok(hipMemset(c->d_pw_heads, 0, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMemset(queue heads)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_begin), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_k0), "hipEventCreate")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_k1), "hipEventCreate")) return bail(VR_ERR_HIP);
@@ -920,6 +953,7 @@ void vr_destroy(vr_ctx* c)
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_present) (void)hipFree(c->d_present);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_pw_heads) (void)hipFree(c->d_pw_heads);
     for (auto* b : c->d_block_counts)
         if (b) (void)hipFree(b);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -1405,7 +1439,7 @@ int vr_volume_layout(vr_ctx* c, int slot, int* flags)
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 11) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 13) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

@@ -103,6 +103,13 @@ struct MarchBatch {
     unsigned n_frames;
 };
 
+// Work queue of the persistent-wavefront kernel (vr_pw.h): eight heads, one per class of the workgroup index modulo 8,
+// zero at launch; heads[c * 64] counts the items of class c handed out beyond every wavefront's first.
+struct PwQueue {
+    unsigned* heads;
+    unsigned n_items;  // logical blocks of the launch (a multiple of 8)
+};
+
 // What enqueue_render decided about one march launch; handed to launch_march of the arithmetic mode's translation unit
 // (vr_launch.h: namespace vr = separately rounded multiply-adds, namespace vrf = fused).
 struct LaunchDesc {
@@ -113,6 +120,11 @@ struct LaunchDesc {
     bool dp_pipe;     // ... with the next round's corner loads software-pipelined
     bool wtb;         // LDS wave-tile kernel (lit shader, separate arithmetic only)
     bool otf;         // lit shader: corner gradients derived from the density plane
+    bool pw;          // persistent wavefronts (vr_pw.h): grid = workgroups of 1024 threads, the packets come from `queue`
+    bool pw_ltf;      // ... with TF slot 0 in LDS (lds_bytes of dynamic LDS)
+    bool pw_pipe;     // ... with the next step's corner loads software-pipelined (lit / unlit shader)
+    unsigned lds_bytes;
+    PwQueue queue;
     dim3 grid, block;
 };
 

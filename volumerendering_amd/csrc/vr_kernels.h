@@ -289,6 +289,29 @@ __device__ __forceinline__ float4 load_vec4(const float4* base, unsigned idx)
         return base[(size_t)idx];
     }
 }
+// The 16-byte voxel `idx` of a volume below 4 GiB as ONE buffer_load_dwordx4 (raw buffer, byte offset in a VGPR, the volume's
+// size as the descriptor's range: an offset beyond it would return zeros instead of faulting).  An intrinsic, so the compiler
+// cannot narrow it: written as a plain float4 load, the lit shader's two uses of a corner -- (z, w) before the per-step
+// vote, (x, y) behind it -- were split into two dwordx2 loads per corner in the persistent kernel (16 vector-memory
+// instructions per sample instead of 8, and the (x, y) halves sunk behind the vote).  -DVR_BUFFER_LOADS=0: plain loads.
+#ifndef VR_BUFFER_LOADS
+#define VR_BUFFER_LOADS 1
+#endif
+typedef unsigned vr_u4 __attribute__((ext_vector_type(4)));
+typedef float vr_f4 __attribute__((ext_vector_type(4)));
+template <bool OFF32>
+__device__ __forceinline__ float4 load_voxel(const DevVolume& v, unsigned idx)
+{
+#if VR_BUFFER_LOADS
+    if constexpr (OFF32) {
+        const unsigned bytes = ((unsigned)v.nx * (unsigned)v.ny * (unsigned)v.nz) << 4;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(v.data), 0, (int)bytes, 0x00020000);
+        const vr_f4 f = __builtin_bit_cast(vr_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx << 4), 0, 0));
+        return make_float4(f.x, f.y, f.z, f.w);
+    }
+#endif
+    return load_vec4<OFF32>(v.data, idx);
+}
 // density of voxel idx: from the scalar plane (a_shift 2) or from the .a lane of the vec4 voxels (a_shift 4, base + 12)
 template <bool OFF32>
 __device__ __forceinline__ float load_a(const DevVolume& v, unsigned idx)
@@ -348,10 +371,10 @@ template <bool OFF32>
 __device__ __forceinline__ void fetch_rgba(const DevVolume& v, f3 p, Fetch4& q, float& fx, float& fy, float& fz)
 {
     Cell c = make_cell(v, p);
-    q.a = load_vec4<OFF32>(v.data, c.o000); q.b = load_vec4<OFF32>(v.data, c.o100);
-    q.d = load_vec4<OFF32>(v.data, c.o010); q.e = load_vec4<OFF32>(v.data, c.o110);
-    q.f = load_vec4<OFF32>(v.data, c.o001); q.g = load_vec4<OFF32>(v.data, c.o101);
-    q.h = load_vec4<OFF32>(v.data, c.o011); q.i = load_vec4<OFF32>(v.data, c.o111);
+    q.a = load_voxel<OFF32>(v, c.o000); q.b = load_voxel<OFF32>(v, c.o100);
+    q.d = load_voxel<OFF32>(v, c.o010); q.e = load_voxel<OFF32>(v, c.o110);
+    q.f = load_voxel<OFF32>(v, c.o001); q.g = load_voxel<OFF32>(v, c.o101);
+    q.h = load_voxel<OFF32>(v, c.o011); q.i = load_voxel<OFF32>(v, c.o111);
     fx = c.fx;
     fy = c.fy;
     fz = c.fz;
@@ -575,6 +598,35 @@ __device__ __forceinline__ TfSample tf_finish(const TfFetch& q)
     return s;
 }
 __device__ __forceinline__ TfSample tf_lookup(const DevTF& tf, float d) { return tf_finish(tf_fetch(tf, d)); }
+// LTF: TF slot 0 read from LDS.  The persistent-wave kernel (vr_pw.h) keeps the padded opacity and colour tables of slot 0,
+// merged into one float4 per entry -- (r, g, b, opacity); the colour texture's own .a is never sampled (`.rgb`,
+// BasicVolumeApp.wgsl:173-175) -- in its workgroup's LDS, so the second dependent round trip of a step (corners, then the
+// texels their density selects) is two ds_read_b128 instead of four L1 look-ups behind the other wavefronts' corner loads.
+// The host asks for it only when the two tables have one resolution (every scene of the reference until a preset of
+// another size is loaded): one index and one weight, as in tf_fetch.  Same texels, same lerps: the same bits.
+extern __shared__ float4 vr_lds_tf[];
+__device__ __forceinline__ TfFetch tf_fetch_lds(const DevTF& tf, float d)
+{
+    const float xo = mad(d, (float)tf.res_o, -0.5f);
+    const float xo0 = floorf(xo);
+    TfFetch q;
+    q.fo = xo - xo0;
+    q.fc = q.fo;
+    const int j = padded_texel(xo0, tf.res_o);
+    q.c0 = vr_lds_tf[j];
+    q.c1 = vr_lds_tf[j + 1];
+    q.o0 = q.c0.w;
+    q.o1 = q.c1.w;
+    return q;
+}
+template <bool LTF>
+__device__ __forceinline__ TfFetch tf_fetch0(const MarchParams& P, float d)
+{
+    if constexpr (LTF) return tf_fetch_lds(P.tf[0], d);
+    else return tf_fetch(P.tf[0], d);
+}
+template <bool LTF>
+__device__ __forceinline__ TfSample tf_lookup0(const MarchParams& P, float d) { return tf_finish(tf_fetch0<LTF>(P, d)); }
 // Pins the point where the texels are first needed: arithmetic on them cannot be moved above this statement, so
 // loads issued before it (the next step's corners) are in flight while the wave waits for the texels.
 __device__ __forceinline__ void tf_pin(TfFetch& q)
@@ -698,13 +750,13 @@ __device__ __forceinline__ void fetch_mask_and_dose(const MarchParams& P, f3 p, 
 
 // The arithmetic of three shaders behind their fetches (sample_src fetches and calls these; sample_and_blend puts its vote
 // between the two).
-template <bool OFF32>
+template <bool OFF32, bool LTF = false>
 __device__ __forceinline__ Src src_inshader(const MarchParams& P, f3 p, f3 w, float ss, float density)
 {
     // BasicVolLightApp.wgsl:209-222 with :212 enabled; ComputeGradient :239-253.  dirs[k] * step = (step, 0, 0) ...:
     // the products with 0 and the additions of the resulting zeros are kept (they are the shader's operations)
     Src o;
-    TfSample t = tf_lookup(P.tf[0], density);
+    TfSample t = tf_lookup0<LTF>(P, density);
     const float d1 = 1.0f * ss, d0 = 0.0f * ss;
     const float rx = tex3_a<OFF32>(P.vol[0], mk3(p.x + d1, p.y + d0, p.z + d0)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d1, p.y - d0, p.z - d0));
     const float ry = tex3_a<OFF32>(P.vol[0], mk3(p.x + d0, p.y + d1, p.z + d0)) - tex3_a<OFF32>(P.vol[0], mk3(p.x - d0, p.y - d1, p.z - d0));
@@ -722,6 +774,7 @@ __device__ __forceinline__ Src src_inshader(const MarchParams& P, f3 p, f3 w, fl
 }
 // (with_rt = false, wave-uniform: the caller knows that no ray of the packet can be masked -- mask is then 0 -- and has
 // not fetched the dose; its table look-up, whose result only a masked sample uses, is left out)
+template <bool LTF = false>
 __device__ __forceinline__ Src src_volume_mask(const MarchParams& P, f3 w, float4 mask, float rt, float4 ct, bool with_rt = true)
 {
     Src o;
@@ -729,7 +782,7 @@ __device__ __forceinline__ Src src_volume_mask(const MarchParams& P, f3 w, float
     trt.rgb = mk3(0.0f, 0.0f, 0.0f);
     trt.opacity = 0.0f;
     if (with_rt) trt = tf_lookup(P.tf[1], rt);
-    TfSample tct = tf_lookup(P.tf[0], ct.w);
+    TfSample tct = tf_lookup0<LTF>(P, ct.w);
     f3 N = normalize3(mk3(ct.x, ct.y, ct.z));
     f3 s = shade(N, w, mk3(0.0f, -5.0f, 0.0f), mk3(0.96f, 0.76f, 0.67f), mk3(1.0f, 1.0f, 1.0f), 1.5f, 0.5f);
     o.rgb = mk3(tct.rgb.x * s.x, tct.rgb.y * s.y, tct.rgb.z * s.z);
@@ -740,10 +793,11 @@ __device__ __forceinline__ Src src_volume_mask(const MarchParams& P, f3 w, float
     }
     return o;
 }
+template <bool LTF = false>
 __device__ __forceinline__ Src src_three_files(const MarchParams& P, float ct, float rt)
 {
     Src o;
-    TfSample tct = tf_lookup(P.tf[0], ct);
+    TfSample tct = tf_lookup0<LTF>(P, ct);
     TfSample trt = tf_lookup(P.tf[1], rt);
     float om = 1.0f - trt.opacity;
     o.rgb = mk3(mad(trt.rgb.x, trt.opacity, tct.rgb.x * om), mad(trt.rgb.y, trt.opacity, tct.rgb.y * om),
@@ -768,19 +822,19 @@ __device__ __forceinline__ void fetch_mask_and_dose(const MarchParams& P, f3 p, 
 
 // (start = the ray's first position and dst_a = the opacity accumulated so far are read by the illustrative shader only,
 // ss = the ray's step size after the variable-step override by the in-shader gradient only)
-template <int V, bool OFF32, bool OTF = false>
+template <int V, bool OFF32, bool OTF = false, bool LTF = false>
 __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 start = f3{0.0f, 0.0f, 0.0f}, float dst_a = 0.0f,
                                           float ss = 0.0f)
 {
     Src o;
     if constexpr (V == V_BASIC) {
         float density = tex3_a<OFF32>(P.vol[0], p);
-        TfSample t = tf_lookup(P.tf[0], density);
+        TfSample t = tf_lookup0<LTF>(P, density);
         o.rgb = t.rgb;
         o.a = t.opacity;
     } else if constexpr (V == V_LIGHT) {
         float4 v = tex3_rgba<OFF32, OTF>(P.vol[0], p);
-        TfSample t = tf_lookup(P.tf[0], v.w);
+        TfSample t = tf_lookup0<LTF>(P, v.w);
         f3 N = normalize3(mk3(v.x, v.y, v.z));
         f3 s = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
                      mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
@@ -788,22 +842,22 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
         o.rgb = mk3(t.rgb.x * s.x, t.rgb.y * s.y, t.rgb.z * s.z);
         o.a = t.opacity;
     } else if constexpr (V == V_LIGHT_INSHADER) {
-        o = src_inshader<OFF32>(P, p, w, ss, tex3_a<OFF32>(P.vol[0], p));
+        o = src_inshader<OFF32, LTF>(P, p, w, ss, tex3_a<OFF32>(P.vol[0], p));
     } else if constexpr (V == V_VOLUME_MASK) {
         const float4 ct = tex3_rgba<OFF32>(P.vol[2], p);
         float4 mask;
         float rt;
         bool any_masked;
         fetch_mask_and_dose<OFF32>(P, p, mask, rt, any_masked);
-        o = src_volume_mask(P, w, mask, rt, ct, any_masked);
+        o = src_volume_mask<LTF>(P, w, mask, rt, ct, any_masked);
     } else if constexpr (V == V_THREE_FILES) {
         const float ct = tex3_a<OFF32>(P.vol[0], p);
         const float rt = tex3_a<OFF32>(P.vol[1], p);
-        o = src_three_files(P, ct, rt);
+        o = src_three_files<LTF>(P, ct, rt);
     } else if constexpr (V == V_MULTI_CTRT) {
         float4 ct = tex3_rgba<OFF32>(P.vol[0], p);
         float rt = tex3_a<OFF32>(P.vol[1], p);
-        TfSample tct = tf_lookup(P.tf[0], ct.w);
+        TfSample tct = tf_lookup0<LTF>(P, ct.w);
         TfSample trt = tf_lookup(P.tf[1], rt);
         float om = 1.0f - trt.opacity;
         f3 col = mk3(mad(trt.rgb.x, trt.opacity, tct.rgb.x * om), mad(trt.rgb.y, trt.opacity, tct.rgb.y * om),
@@ -817,7 +871,7 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     } else if constexpr (V == V_ILLUSTRATIVE) {  // MutliCTRTIllustrative.wgsl:271-310
         float4 ct = tex3_rgba<OFF32>(P.vol[0], p);
         float rt = tex3_a<OFF32>(P.vol[1], p);
-        TfSample tct = tf_lookup(P.tf[0], ct.w);
+        TfSample tct = tf_lookup0<LTF>(P, ct.w);
         TfSample trt = tf_lookup(P.tf[1], rt);
         float om = 1.0f - trt.opacity;
         f3 col = mk3(mad(trt.rgb.x, trt.opacity, tct.rgb.x * om), mad(trt.rgb.y, trt.opacity, tct.rgb.y * om),
@@ -840,7 +894,7 @@ __device__ __forceinline__ Src sample_src(const MarchParams& P, f3 p, f3 w, f3 s
     } else {  // V_TF_CALIB
         float density = tex3_a<OFF32>(P.vol[0], p);
         float4 mask = tex3_nearest<OFF32>(P.vol[1], p);
-        TfSample t = tf_lookup(P.tf[0], density);
+        TfSample t = tf_lookup0<LTF>(P, density);
         if (mask.x > 0.0f) {
             t.rgb = mk3(1.0f, 1.0f, 0.0f);
             t.opacity = 0.1f;
@@ -858,17 +912,56 @@ __device__ __forceinline__ bool opacity_is_zero(const MarchParams& P, float d)
     return (d - d == 0.0f) && jo <= P.zskip_prefix;  // finite: an infinite density has a NaN weight, hence a NaN opacity
 }
 
+// The lit shader from the interpolated voxel to the blend (BasicVolLightApp.wgsl:216-223), on (x, y) / (r, g) register pairs
+// so that the packed instructions need no shuffling; per component the operations and their order are those of
+// normalize3 / shade / blend.  zw = (gradient z, density), gxy = (gradient x, gradient y), tq = the table texels of `density`.
+__device__ __forceinline__ void light_shade_blend(const MarchParams& P, f3 w, v2f zw, v2f gxy, const TfFetch& tq, float4& dst)
+{
+    v2f Lxy = v2f{P.light_pos[0] - w.x, P.light_pos[1] - w.y};
+    float Lz = P.light_pos[2] - w.z;
+#if VR_FUSED
+    const v2f inv = inv_sqrt_exact2(mad(zw.x, zw.x, mad(gxy.y, gxy.y, gxy.x * gxy.x)), mad(Lz, Lz, mad(Lxy.y, Lxy.y, Lxy.x * Lxy.x)));
+#else
+    const v2f g2 = gxy * gxy, l2 = Lxy * Lxy;
+    const v2f inv = inv_sqrt_exact2((g2.x + g2.y) + zw.x * zw.x, (l2.x + l2.y) + Lz * Lz);
+#endif
+    const float inv_g = inv.x, inv_l = inv.y;  // (the two normalisations' 1 / length, computed side by side)
+    const v2f Nxy = gxy * inv_g;
+    const float Nz = zw.x * inv_g;
+    Lxy = Lxy * inv_l;
+    Lz = Lz * inv_l;
+#if VR_FUSED
+    const float m = max0(mad(Nz, Lz, mad(Nxy.y, Lxy.y, Nxy.x * Lxy.x)));
+#else
+    const v2f nl = Nxy * Lxy;
+    const float m = max0((nl.x + nl.y) + Nz * Lz);
+#endif
+    const v2f sh_rg = mad2(v2f{P.light_dif[0], P.light_dif[1]} * m, v2f{2.5f, 2.5f}, v2f{P.light_amb[0], P.light_amb[1]} * 0.5f);
+    const float sh_b = mad(P.light_dif[2] * m, 2.5f, P.light_amb[2] * 0.5f);
+    const float opacity = lerpf(tq.o0, tq.o1, tq.fo);
+    const v2f c_rg = lerp2(v2f{tq.c0.x, tq.c0.y}, v2f{tq.c1.x, tq.c1.y}, tq.fc);
+    const float c_b = lerpf(tq.c0.z, tq.c1.z, tq.fc);
+    const v2f src_rg = (c_rg * sh_rg) * opacity;  // FrontToBackBlend: (rgb * a, a)
+    const float src_b = (c_b * sh_b) * opacity;
+    const float om = 1.0f - dst.w;
+    const v2f d_rg = mad2(src_rg, v2f{om, om}, v2f{dst.x, dst.y});
+    dst.x = d_rg.x;
+    dst.y = d_rg.y;
+    dst.z = mad(om, src_b, dst.z);
+    dst.w = mad(om, opacity, dst.w);
+}
+
 // ZSKIP (the host has verified what exact empty-space skipping needs: finite colour table and light, SKIP kernels only):
 // when the opacity of EVERY ray of the packet is exactly 0 at this step, the blend is the identity for all of them (rgb
 // finite, rgb * 0 = 0, dst + (1 - dst.a) * 0 = dst) and the table texels, the gradient, the shade and the blend are not
 // computed -- the cells of an active brick that lie in air, before the rays reach the body.  One vote per step.
-template <int V, bool OFF32, bool OTF = false, bool ZSKIP = false>
+template <int V, bool OFF32, bool OTF = false, bool ZSKIP = false, bool LTF = false>
 __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 w, float4& dst, f3 start, float ss)
 {
     if constexpr (V == V_BASIC && ZSKIP) {
         const float density = tex3_a<OFF32>(P.vol[0], p);
         if (__ballot(!opacity_is_zero(P, density)) == 0) return;
-        const TfSample t = tf_lookup(P.tf[0], density);
+        const TfSample t = tf_lookup0<LTF>(P, density);
         blend(t.rgb, t.opacity, dst);
     } else if constexpr (V == V_LIGHT) {
         // sample_src<V_LIGHT> + blend, written on (x, y) / (r, g) register pairs from the interpolation to the blend so
@@ -882,40 +975,9 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         if constexpr (ZSKIP) {
             if (__ballot(!opacity_is_zero(P, zw.y)) == 0) return;
         }
-        const TfFetch tq = tf_fetch(P.tf[0], zw.y);
+        const TfFetch tq = tf_fetch0<LTF>(P, zw.y);
         const v2f gxy = interp_xy(q, fx, fy, fz);
-        v2f Lxy = v2f{P.light_pos[0] - w.x, P.light_pos[1] - w.y};
-        float Lz = P.light_pos[2] - w.z;
-#if VR_FUSED
-        const v2f inv = inv_sqrt_exact2(mad(zw.x, zw.x, mad(gxy.y, gxy.y, gxy.x * gxy.x)), mad(Lz, Lz, mad(Lxy.y, Lxy.y, Lxy.x * Lxy.x)));
-#else
-        const v2f g2 = gxy * gxy, l2 = Lxy * Lxy;
-        const v2f inv = inv_sqrt_exact2((g2.x + g2.y) + zw.x * zw.x, (l2.x + l2.y) + Lz * Lz);
-#endif
-        const float inv_g = inv.x, inv_l = inv.y;  // (the two normalisations' 1 / length, computed side by side)
-        const v2f Nxy = gxy * inv_g;
-        const float Nz = zw.x * inv_g;
-        Lxy = Lxy * inv_l;
-        Lz = Lz * inv_l;
-#if VR_FUSED
-        const float m = max0(mad(Nz, Lz, mad(Nxy.y, Lxy.y, Nxy.x * Lxy.x)));
-#else
-        const v2f nl = Nxy * Lxy;
-        const float m = max0((nl.x + nl.y) + Nz * Lz);
-#endif
-        const v2f sh_rg = mad2(v2f{P.light_dif[0], P.light_dif[1]} * m, v2f{2.5f, 2.5f}, v2f{P.light_amb[0], P.light_amb[1]} * 0.5f);
-        const float sh_b = mad(P.light_dif[2] * m, 2.5f, P.light_amb[2] * 0.5f);
-        const float opacity = lerpf(tq.o0, tq.o1, tq.fo);
-        const v2f c_rg = lerp2(v2f{tq.c0.x, tq.c0.y}, v2f{tq.c1.x, tq.c1.y}, tq.fc);
-        const float c_b = lerpf(tq.c0.z, tq.c1.z, tq.fc);
-        const v2f src_rg = (c_rg * sh_rg) * opacity;  // FrontToBackBlend: (rgb * a, a)
-        const float src_b = (c_b * sh_b) * opacity;
-        const float om = 1.0f - dst.w;
-        const v2f d_rg = mad2(src_rg, v2f{om, om}, v2f{dst.x, dst.y});
-        dst.x = d_rg.x;
-        dst.y = d_rg.y;
-        dst.z = mad(om, src_b, dst.z);
-        dst.w = mad(om, opacity, dst.w);
+        light_shade_blend(P, w, zw, gxy, tq, dst);
     } else {
         if constexpr (ZSKIP && (V == V_VOLUME_MASK || V == V_THREE_FILES || V == V_LIGHT_INSHADER)) {
             // the same vote for the other shaders whose opacity is the CT table's alone: all the step's fetches are issued as
@@ -929,23 +991,23 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
                 fetch_mask_and_dose<OFF32>(P, p, mask, rt, any_masked);
                 const bool inert = !(mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) && opacity_is_zero(P, ct.w);
                 if (__ballot(!inert) == 0) return;
-                const Src s = src_volume_mask(P, w, mask, rt, ct, any_masked);
+                const Src s = src_volume_mask<LTF>(P, w, mask, rt, ct, any_masked);
                 blend(s.rgb, s.a, dst);
             } else if constexpr (V == V_THREE_FILES) {
                 const float ct = tex3_a<OFF32>(P.vol[0], p);
                 const float rt = tex3_a<OFF32>(P.vol[1], p);
                 if (__ballot(!opacity_is_zero(P, ct)) == 0) return;
-                const Src s = src_three_files(P, ct, rt);
+                const Src s = src_three_files<LTF>(P, ct, rt);
                 blend(s.rgb, s.a, dst);
             } else {
                 const float density = tex3_a<OFF32>(P.vol[0], p);
                 if (__ballot(!opacity_is_zero(P, density)) == 0) return;
-                const Src s = src_inshader<OFF32>(P, p, w, ss, density);
+                const Src s = src_inshader<OFF32, LTF>(P, p, w, ss, density);
                 blend(s.rgb, s.a, dst);
             }
             return;
         }
-        const Src s = sample_src<V, OFF32, OTF>(P, p, w, start, dst.w, ss);
+        const Src s = sample_src<V, OFF32, OTF, LTF>(P, p, w, start, dst.w, ss);
         blend(s.rgb, s.a, dst);
     }
 }
@@ -987,10 +1049,10 @@ __device__ __forceinline__ const MarchParams& frame_params(const MarchBatch& B)
     return B.frame[g - batch_group(g, n) * n];
 }
 
-__device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
+// (lb = logical block, wpb = wavefronts per block, wib = this wavefront's index in its block)
+__device__ __forceinline__ PixelSlot map_pixel_at(const MarchParams& P, int lb, int wpb, int wib)
 {
     PixelSlot s;
-    const int lb = logical_block(P);
     // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD; speed only, never
     // correctness).  The 16 blocks of one 64x64 tile stay on ONE XCD (their rays traverse neighbouring voxels:
     // shared L2 lines), while consecutive tiles go to different XCDs so that every XCD gets an even share of the
@@ -998,12 +1060,12 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
     // A block is 1 or 4 wavefronts (blockDim.x 64 / 256); a tile is 64 packets of 8x8 pixels either way, packet
     // pk = 4 * (16x16 sub-block) + quadrant.
     const int xcd = lb & 7, q = lb >> 3;
-    const int wpb = blockDim.x >> 6, bpt = 64 / wpb;  // wavefronts per block, blocks per tile
+    const int bpt = 64 / wpb;  // blocks per tile
     int n = xcd + 8 * (q / bpt);  // ordinal of the owned tile this block works on
-    int pk = (q % bpt) * wpb + (threadIdx.x >> 6);
+    int pk = (q % bpt) * wpb + wib;
     if (P.xcd_mode == 1) {  // consecutive blocks of a tile on consecutive XCDs: every XCD gets an even sample of the screen
         n = lb / bpt;
-        pk = (lb % bpt) * wpb + (threadIdx.x >> 6);
+        pk = (lb % bpt) * wpb + wib;
     }
     const int sub = pk >> 2;
     const bool in_launch = n < P.n_tiles;
@@ -1019,6 +1081,10 @@ __device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
     s.active = in_launch && (s.px < P.W) && (s.py < P.H) && (P.only_tile < 0 || P.only_tile == n);
     s.out_index = P.packed ? (n * (kTile * kTile) + tpy * kTile + tpx) : (s.py * P.W + s.px);
     return s;
+}
+__device__ __forceinline__ PixelSlot map_pixel(const MarchParams& P)
+{
+    return map_pixel_at(P, logical_block(P), (int)(blockDim.x >> 6), (int)(threadIdx.x >> 6));
 }
 
 // Exact empty-space test for the brick (kBrickCells^3 cells) that contains the base cell of p (vol[0]).
@@ -1196,15 +1262,13 @@ __device__ __forceinline__ int steps_inside(f3 p, f3 step, float bx0, float by0,
 
 // OTF (V_LIGHT only): the corners' gradients are derived from the density plane (fetch_rgba_otf) instead of read from
 // the vec4 voxels; the host asks for it when the volume's .rgb is verified to be PreComputeGradient(false) of its .a.
-template <int V, bool OFF32, bool SKIP, int LEAP, bool OTF = false, bool BATCH = false>
-__global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kernel(const MarchBatch B)
+// The whole march of one ray (ray set-up, per-pixel prologue, the loop): what a lane does for its pixel `slot`.  Shared by
+// march_kernel (one packet per wavefront of the grid) and march_pw_kernel (vr_pw.h: persistent wavefronts that take packet
+// after packet from a queue; LTF = transfer-function slot 0 read from the workgroup's LDS).
+template <int V, bool OFF32, bool SKIP, int LEAP, bool OTF, bool LTF>
+__device__ __forceinline__ void march_packet(const MarchParams& P, const PixelSlot& slot, float4& dst, unsigned& blends,
+                                             unsigned& covered, unsigned& fetched)
 {
-    const MarchParams& P = frame_params<BATCH>(B);
-    const unsigned long long t_start = wall_clock64();
-    PixelSlot slot = map_pixel(P);
-    float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    unsigned blends = 0, covered = 0, fetched = 0;
-
     if (slot.active && slot.px >= P.rect[0] && slot.px <= P.rect[2] && slot.py >= P.rect[1] && slot.py <= P.rect[3]) {
         Ray ray = setup_ray(P, slot.px, slot.py);
         if (ray.hit) {
@@ -1351,17 +1415,22 @@ __global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kern
                                 // loads in flight; the look-ahead byte is taken before them for the same reason.
                                 unsigned R = 0;
                                 if constexpr (SKIP) R = dist_at(P, brick_of<OFF32>(P, pq));
-                                TfFetch tq;
-                                f3 grad = mk3(0.0f, 0.0f, 0.0f);
+                                TfFetch tq = {};
+                                v2f zw = v2f{0.0f, 0.0f}, gxy = zw;
+                                bool all_zero = false;  // the per-step vote of sample_and_blend (ZSKIP)
                                 if constexpr (V == V_LIGHT) {
                                     if (!have) fetch_rgba<OFF32>(P.vol[0], p, F4, wfx, wfy, wfz);
-                                    const v2f zw = interp_zw(F4, wfx, wfy, wfz);
-                                    tq = tf_fetch(P.tf[0], zw.y);
-                                    const v2f xy = interp_xy(F4, wfx, wfy, wfz);
-                                    grad = mk3(xy.x, xy.y, zw.x);
+                                    zw = interp_zw(F4, wfx, wfy, wfz);
+                                    if constexpr (SKIP) all_zero = __ballot(!opacity_is_zero(P, zw.y)) == 0;
+                                    if (!all_zero) {
+                                        tq = tf_fetch0<LTF>(P, zw.y);
+                                        gxy = interp_xy(F4, wfx, wfy, wfz);
+                                    }
                                 } else {
                                     if (!have) fetch_a<OFF32>(P.vol[0], p, F1, wfx, wfy, wfz);
-                                    tq = tf_fetch(P.tf[0], interp_a(F1, wfx, wfy, wfz));
+                                    zw.y = interp_a(F1, wfx, wfy, wfz);
+                                    if constexpr (SKIP) all_zero = __ballot(!opacity_is_zero(P, zw.y)) == 0;
+                                    if (!all_zero) tq = tf_fetch0<LTF>(P, zw.y);
                                 }
                                 if constexpr (SKIP) {
                                     asm volatile("" : "+v"(R));
@@ -1373,20 +1442,18 @@ __global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kern
                                 else
                                     fetch_a<OFF32>(P.vol[0], pn, F1, wfx, wfy, wfz);
                                 __builtin_amdgcn_sched_barrier(0);
-                                tf_pin(tq);
                                 have = true;
-                                const TfSample t = tf_finish(tq);
-                                if constexpr (V == V_LIGHT) {
-                                    const f3 N = normalize3(grad);
-                                    const f3 sh = shade(N, w, mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]),
-                                                        mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
-                                                        mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f);
-                                    blend(mk3(t.rgb.x * sh.x, t.rgb.y * sh.y, t.rgb.z * sh.z), t.opacity, dst);
-                                } else {
-                                    blend(t.rgb, t.opacity, dst);
+                                if (!all_zero) {
+                                    if constexpr (!LTF) tf_pin(tq);  // (texels from LDS are waited for with their own counter)
+                                    if constexpr (V == V_LIGHT) {
+                                        light_shade_blend(P, w, zw, gxy, tq, dst);
+                                    } else {
+                                        const TfSample t = tf_finish(tq);
+                                        blend(t.rgb, t.opacity, dst);
+                                    }
                                 }
                             } else {
-                                sample_and_blend<V, OFF32, OTF, SKIP>(P, p, w, dst, ray.start, step_size);
+                                sample_and_blend<V, OFF32, OTF, SKIP, LTF>(P, p, w, dst, ray.start, step_size);
                             }
                             ++fetched;
                             ++blends;
@@ -1458,6 +1525,18 @@ __global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kern
             }
         }
     }
+}
+
+template <int V, bool OFF32, bool SKIP, int LEAP, bool OTF = false, bool BATCH = false>
+__global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kernel(const MarchBatch B)
+{
+    const MarchParams& P = frame_params<BATCH>(B);
+    const unsigned long long t_start = wall_clock64();
+    PixelSlot slot = map_pixel(P);
+    float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    unsigned blends = 0, covered = 0, fetched = 0;
+
+    march_packet<V, OFF32, SKIP, LEAP, OTF, false>(P, slot, dst, blends, covered, fetched);
 
     // packed-tile launches write every slot of an owned tile (pixels outside the viewport = 0)
     if (slot.active || (P.packed && slot.in_launch)) P.out[slot.out_index] = dst;
@@ -1583,10 +1662,14 @@ __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks, unsi
 constexpr int kOrderMaxBlocks = 192 * 1024;  // launches with more blocks keep the index order (C5, one wavefront per block: 130 560)
 // It also reports how long the launch took: last workgroup end - first workgroup start of the records it reads (100 MHz
 // ticks, to host-visible memory; vr_kernel_times).  Timing events around every launch cost the frame's stream 11 us.
+// pw_heads: the queue heads of the persistent-wavefront launch whose records these are (vr_pw.h) -- cleared here, behind that
+// launch, for the next launch that uses the slot.
 __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long long* __restrict__ in, int n_blocks,
                                                             unsigned* __restrict__ order, unsigned* __restrict__ longest_chain,
-                                                            unsigned long long* __restrict__ span_ticks)
+                                                            unsigned long long* __restrict__ span_ticks,
+                                                            unsigned* __restrict__ pw_heads)
 {
+    if (pw_heads != nullptr && threadIdx.x < 8) pw_heads[threadIdx.x * 64] = 0u;
     __shared__ unsigned hist[1024];  // [class 0..7][bucket 0..127]
     __shared__ unsigned base[1024];
     __shared__ unsigned chain_max;

@@ -6,6 +6,7 @@
 #include "../../include/vr.h"
 #include "vr_kernels.h"
 #include "vr_dp.h"
+#include "vr_pw.h"
 #if !VR_FUSED
 #include "vr_wtb.h"
 #endif
@@ -70,9 +71,67 @@ void launch_dp(bool off32, dim3 grid, dim3 block, hipStream_t s, const MarchBatc
 #undef VR_LAUNCH_DP
 }
 
+// persistent wavefronts (vr_pw.h); the loop form is march_kernel's default (runs through inert bricks when skipping)
+template <int V>
+void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
+{
+    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK || V == V_LIGHT_INSHADER);
+    const bool skip = kCanSkip && B.frame[0].brick_dist != nullptr;
+#define VR_LAUNCH_PW(O, S, T, PP)                                                                                      \
+    do {                                                                                                               \
+        auto k = march_pw_kernel<V, O, S, T, PP>;                                                                      \
+        if (L.lds_bytes > 48u * 1024u) {                                                                               \
+            static unsigned raised = 0;  /* per instantiation: the attribute sticks to the function */                 \
+            if (L.lds_bytes > raised) {                                                                                \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,\
+                                          (int)L.lds_bytes);                                                           \
+                raised = L.lds_bytes;                                                                                  \
+            }                                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(k, L.grid, L.block, L.lds_bytes, s, B, L.queue);                                            \
+    } while (0)
+#define VR_LAUNCH_PW_T(O, S)                                                                                           \
+    do {                                                                                                               \
+        if constexpr (kCanPipe) {                                                                                      \
+            if (L.pw_pipe) {                                                                                           \
+                if (L.pw_ltf) VR_LAUNCH_PW(O, S, true, true);                                                          \
+                else VR_LAUNCH_PW(O, S, false, true);                                                                  \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (L.pw_ltf) VR_LAUNCH_PW(O, S, true, false);                                                                 \
+        else VR_LAUNCH_PW(O, S, false, false);                                                                         \
+    } while (0)
+    constexpr bool kCanPipe = (V == V_BASIC || V == V_LIGHT);
+    if constexpr (kCanSkip) {
+        if (skip) {
+            if (L.off32) VR_LAUNCH_PW_T(true, true);
+            else VR_LAUNCH_PW_T(false, true);
+            return;
+        }
+    }
+    if (L.off32) VR_LAUNCH_PW_T(true, false);
+    else VR_LAUNCH_PW_T(false, false);
+#undef VR_LAUNCH_PW_T
+#undef VR_LAUNCH_PW
+}
+
 void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 {
     const int variant = L.variant;
+    if (L.pw) {
+        switch (variant) {
+        case VR_VARIANT_BASIC: launch_pw<V_BASIC>(L, s, B); break;
+        case VR_VARIANT_LIGHT: launch_pw<V_LIGHT>(L, s, B); break;
+        case VR_VARIANT_VOLUME_MASK: launch_pw<V_VOLUME_MASK>(L, s, B); break;
+        case VR_VARIANT_THREE_FILES: launch_pw<V_THREE_FILES>(L, s, B); break;
+        case VR_VARIANT_MULTI_CTRT: launch_pw<V_MULTI_CTRT>(L, s, B); break;
+        case VR_VARIANT_ILLUSTRATIVE: launch_pw<V_ILLUSTRATIVE>(L, s, B); break;
+        case VR_VARIANT_LIGHT_INSHADER: launch_pw<V_LIGHT_INSHADER>(L, s, B); break;
+        default: launch_pw<V_TF_CALIB>(L, s, B); break;
+        }
+        return;
+    }
     const bool off32 = L.off32, dp_pipe = L.dp_pipe, otf = L.otf;
     const int leap_mode = L.leap_mode, dp = L.dp;
     const dim3 grid = L.grid, block = L.block;
@@ -97,7 +156,8 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
             case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 4, false>(off32, grid, block, s, B); break;
             case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 4, false>(off32, grid, block, s, B); break;
             case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 4, false>(off32, grid, block, s, B); break;
-            default: launch_dp<V_TF_CALIB, 4, false>(off32, grid, block, s, B); break;
+            case VR_VARIANT_TF_CALIB: launch_dp<V_TF_CALIB, 4, false>(off32, grid, block, s, B); break;
+            default: break;  // (no depth-parallel form of this shader: enqueue_render never asks for one)
             }
         } else if (dp == 2) {
             switch (variant) {
@@ -109,7 +169,8 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
             case VR_VARIANT_VOLUME_MASK: launch_dp<V_VOLUME_MASK, 2, false>(off32, grid, block, s, B); break;
             case VR_VARIANT_THREE_FILES: launch_dp<V_THREE_FILES, 2, false>(off32, grid, block, s, B); break;
             case VR_VARIANT_MULTI_CTRT: launch_dp<V_MULTI_CTRT, 2, false>(off32, grid, block, s, B); break;
-            default: launch_dp<V_TF_CALIB, 2, false>(off32, grid, block, s, B); break;
+            case VR_VARIANT_TF_CALIB: launch_dp<V_TF_CALIB, 2, false>(off32, grid, block, s, B); break;
+            default: break;  // (no depth-parallel form of this shader: enqueue_render never asks for one)
             }
         } else
         switch (variant) {
