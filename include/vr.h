@@ -249,6 +249,12 @@ int vr_download(vr_ctx* ctx, float* frag_rgba, uint8_t* present_bgra8, uint64_t*
  * synchronised; the same arithmetic as vr_download's present_bgra8.                                               */
 int vr_present_async(vr_ctx* ctx, const void* d_frame, void* d_bgra8, void* stream);
 
+/* vr_present_async for the root of a multi-GPU gather: presents straight from the gathered, tile-major segments
+ * (layout as vr_unpack_tiles_strided_async; rank_stride_tiles <= 0 = segments back to back) into `d_bgra8` (W*H*4 bytes,
+ * row-major), so a viewer that only wants the presented frame needs no un-permuted float frame in between.  Replaces the
+ * same output merge (App/src/renderer/PipelineBuilder.cpp:142-154); bit-identical to vr_unpack_tiles_async + vr_present_async. */
+int vr_present_tiles_async(vr_ctx* ctx, const void* d_gathered, int world, int rank_stride_tiles, void* d_bgra8, void* stream);
+
 /* Packed tiles of the last vr_render_tiles (host copy). */
 int vr_download_tiles(vr_ctx* ctx, float* tiles_rgba, uint64_t* composited_samples);
 

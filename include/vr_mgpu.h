@@ -98,6 +98,33 @@ int vr_mgpu_reduce(vr_mgpu* m, uint64_t counters_sum[3], double local_value, dou
 /* Which transport the gather uses, for reports: "RCCL <version> ncclGather".                                      */
 const char* vr_mgpu_backend(const vr_mgpu* m);
 
+/* Ranks RCCL itself sees in the communicator (ncclCommCount, /opt/rocm/include/rccl/rccl.h), and the HIP device local rank
+ * `local_rank` renders on: what a report should print beside `world`, so that a run describes the partition it really had.  */
+int vr_mgpu_comm_count(const vr_mgpu* m);
+int vr_mgpu_device(const vr_mgpu* m, int local_rank);
+
+/* What the root produces from the gathered segments of every launch (default VR_MGPU_OUT_FRAME):
+ *   VR_MGPU_OUT_FRAME    the assembled W x H float frames (vr_unpack_tiles_strided_async: one un-permute pass per frame,
+ *                        16 B read + 16 B written per pixel) -- vr_mgpu_frame_device_ptr / vr_mgpu_download
+ *   VR_MGPU_OUT_PRESENT  the presented BGRA8Unorm frames (the output merge of App/src/renderer/PipelineBuilder.cpp:142-154
+ *                        over the white background), written by vr_present_tiles_async straight from the tile-major
+ *                        segments: a viewer that only shows the frame needs no un-permuted float frame at all --
+ *                        vr_mgpu_present_device_ptr / vr_mgpu_download_present
+ * Both bits may be set.  Takes effect with the next launch; same value on every rank.                              */
+#define VR_MGPU_OUT_FRAME 1
+#define VR_MGPU_OUT_PRESENT 2
+int vr_mgpu_set_output(vr_mgpu* m, int output);
+void* vr_mgpu_present_device_ptr(vr_mgpu* m, int which, int frame_in_launch);
+int vr_mgpu_download_present(vr_mgpu* m, int which, int frame_in_launch, uint8_t* bgra8);
+
+/* Stage timeline of a rank (instrumentation; off by default: timing events cost each launch's streams a few microseconds).
+ * With it on, every launch records four events; vr_mgpu_stage_times waits for the last launch into buffer set `which`
+ * and returns, in milliseconds, ms[0] = march (render start .. tiles rendered), ms[1] = gather (tiles rendered .. segments
+ * on the root / sent), ms[2] = output (un-permute and / or present on the root; ~0 elsewhere), ms[3] = start .. end.
+ * vr_mgpu_set_stage_timing drains the pipeline.                                                                    */
+int vr_mgpu_set_stage_timing(vr_mgpu* m, int enabled);
+int vr_mgpu_stage_times(vr_mgpu* m, int local_rank, int which, float ms[4]);
+
 #ifdef __cplusplus
 }
 #endif

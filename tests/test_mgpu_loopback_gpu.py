@@ -168,3 +168,48 @@ def test_several_frames_per_launch(lib, world):
         assert comp == refs[3][1] and covered == refs[3][2]
         with pytest.raises(capi.VrError):
             m.frames_async(capi.LIGHT, us[:5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_root_presents_through_the_permutation(lib, world):
+    """VR_MGPU_OUT_PRESENT: the root writes the presented BGRA8 frame straight from the gathered tile-major segments
+    (vr_present_tiles_async) -- equal, byte for byte, to un-permuting first and presenting the assembled frame
+    (vr_download's present of the single-GPU render); with both outputs on, the float frame is still there.  Also the
+    per-stage timeline, ncclCommCount and the device query."""
+    W, H = 200, 150
+    yaws = [0.3, 1.2, 2.0]
+    step, count = hr.stepping_params(24, 24, 24)
+    us = [vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=y)) for y in yaws]
+    refs = []
+    with capi.Context(W, H, 0) as ctx:
+        scene(ctx, W, H, capi.LIGHT)
+        for u in us:
+            ctx.set_uniforms(u)
+            ctx.render(capi.LIGHT)
+            frag, bgra, _ = ctx.download(present=True)
+            refs.append((frag, bgra))
+    with mgpu.MultiGpu.local(W, H, [0] * world, _lib=lib) as m:
+        assert m.comm_count() == world and [m.device(r) for r in range(world)] == [0] * world
+        for r in range(world):
+            scene(m.context(r), W, H, capi.LIGHT)
+        m.set_output(mgpu.OUT_PRESENT)
+        m.set_stage_timing(True)
+        b = m.frames_async(capi.LIGHT, us)
+        for f in range(3):
+            assert np.array_equal(m.download_present(b, f, W, H), refs[f][1]), f
+        march, gather, output, total = m.stage_times(0, b)
+        assert march > 0 and gather >= 0 and output > 0 and total >= march + output - 1e-3
+        if world > 1:
+            assert m.stage_times(world - 1, b)[0] > 0
+        m.set_output(mgpu.OUT_FRAME | mgpu.OUT_PRESENT)
+        for r in range(world):
+            m.context(r).set_uniforms(us[1])
+        b = m.frame_async(capi.LIGHT)
+        assert np.array_equal(m.download_present(b, 0, W, H), refs[1][1])
+        assert np.array_equal(vt.bits(m.download(b, W, H)), vt.bits(refs[1][0]))
+        m.set_stage_timing(False)
+        with pytest.raises(capi.VrError):
+            m.stage_times(0, b)
+        with pytest.raises(capi.VrError):
+            m.set_output(0)

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "vr_render_batch_async", "vr_render_tiles_batch_async", "vr_unpack_tiles_strided_async",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
     "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream", "vr_hint_frames_in_flight",
-    "vr_set_kernel_timing",
+    "vr_set_kernel_timing", "vr_present_tiles_async",
 ]
 
 
@@ -115,6 +115,7 @@ def load() -> C.CDLL:
     lib.vr_set_volume_layout.argtypes = [vp, i32]
     lib.vr_set_arithmetic.argtypes = [vp, i32]
     lib.vr_present_async.argtypes = [vp, vp, vp, vp]
+    lib.vr_present_tiles_async.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.vr_hint_frames_in_flight.argtypes = [vp, i32]
     lib.vr_stream.argtypes = [vp, i32]
     lib.vr_stream.restype = vp
@@ -322,6 +323,10 @@ class Context:
     def present_async(self, d_bgra8: int, d_frame: int = 0, stream: int = 0):
         """BGRA8Unorm present of a device frame into device memory (what a GL / Vulkan interop buffer would be)."""
         self._chk(self.lib.vr_present_async(self.h, d_frame, d_bgra8, stream))
+
+    def present_tiles_async(self, d_gathered: int, world: int, d_bgra8: int, rank_stride_tiles: int = 0, stream: int = 0):
+        """vr_present_tiles_async: BGRA8 frame straight from gathered tile-major segments (device pointers)."""
+        self._chk(self.lib.vr_present_tiles_async(self.h, d_gathered, world, rank_stride_tiles, d_bgra8, stream))
 
     def set_arithmetic(self, mode: int):
         """ARITH_SEPARATE (0, default) or ARITH_FUSED (1): per-sample a * b + c with two roundings or one (include/vr.h)."""

@@ -34,6 +34,10 @@ struct Rank {
     float* tiles[kSlots] = {};     // this rank's packed tiles (segment padded to the largest rank's), batch_cap frames of them
     float* gathered[kSlots] = {};  // root: world x batch_cap segments
     float* frame[kSlots] = {};     // root: batch_cap assembled W x H frames, back to back
+    uint32_t* present[kSlots] = {};  // root, VR_MGPU_OUT_PRESENT: batch_cap presented BGRA8 frames, back to back
+    // stage timeline (vr_mgpu_set_stage_timing): render start, render done, segments gathered, output written
+    hipEvent_t tm_t0[kSlots] = {}, tm_r[kSlots] = {}, tm_g[kSlots] = {}, tm_d[kSlots] = {};
+    bool tm_valid[kSlots] = {};
     unsigned long long* d_red = nullptr;  // 4 x 8 bytes for vr_mgpu_reduce
 };
 
@@ -48,6 +52,10 @@ struct vr_mgpu {
     int batch_cap = 1;      // frames per launch the buffer sets are sized for (grown on demand by vr_mgpu_frames_async)
     int exp_share = 1;      // experiment (VR_MGPU_EXP_SHARE=N, world of one only): render and gather only rank 0's share of an
                             // N-rank partition -- the timeline of one rank of an N-GPU run on a one-GPU box; frames are incomplete
+    int output = VR_MGPU_OUT_FRAME;  // what the root produces from the gathered segments (vr_mgpu_set_output)
+    bool stage_timing = false;       // timing events around the three stages of every launch (vr_mgpu_set_stage_timing)
+    bool failed = false;             // a collective or an allocation failed half-way: the ranks' queues no longer match up,
+                                     // every later call returns the stored error
     unsigned long long frame_no = 0;
     std::string err, backend;
 };
@@ -92,8 +100,11 @@ int alloc_buffers(vr_mgpu* m, Rank& k)
         if (k.tiles[b]) (void)hipFree(k.tiles[b]);
         if (k.gathered[b]) (void)hipFree(k.gathered[b]);
         if (k.frame[b]) (void)hipFree(k.frame[b]);
+        if (k.present[b]) (void)hipFree(k.present[b]);
         k.tiles[b] = k.gathered[b] = k.frame[b] = nullptr;
+        k.present[b] = nullptr;
         k.used[b] = false;
+        k.tm_valid[b] = false;
         MG_HIP(m, hipMalloc(&k.tiles[b], seg * sizeof(float)));
         MG_HIP(m, hipMemset(k.tiles[b], 0, seg * sizeof(float)));
         if (k.rank == 0) {
@@ -101,6 +112,8 @@ int alloc_buffers(vr_mgpu* m, Rank& k)
             MG_HIP(m, hipMemset(k.gathered[b], 0, seg * (size_t)gather_world * sizeof(float)));
             MG_HIP(m, hipMalloc(&k.frame[b], frame_floats * sizeof(float)));
             MG_HIP(m, hipMemset(k.frame[b], 0, frame_floats * sizeof(float)));
+            MG_HIP(m, hipMalloc(&k.present[b], frame_floats));  // (4 bytes per pixel = one float's worth)
+            MG_HIP(m, hipMemset(k.present[b], 0, frame_floats));
         }
     }
     MG_HIP(m, hipDeviceSynchronize());
@@ -117,6 +130,10 @@ int setup_rank(vr_mgpu* m, Rank& k)
         if (!k.s_render[b]) return fail(m, VR_ERR_HIP, "vr_stream: no render stream available");
         MG_HIP(m, hipEventCreateWithFlags(&k.ev_render[b], hipEventDisableTiming));
         MG_HIP(m, hipEventCreateWithFlags(&k.ev_gathered[b], hipEventDisableTiming));
+        MG_HIP(m, hipEventCreate(&k.tm_t0[b]));
+        MG_HIP(m, hipEventCreate(&k.tm_r[b]));
+        MG_HIP(m, hipEventCreate(&k.tm_g[b]));
+        MG_HIP(m, hipEventCreate(&k.tm_d[b]));
     }
     int rc = alloc_buffers(m, k);
     if (rc != VR_OK) return rc;
@@ -255,6 +272,9 @@ void vr_mgpu_destroy(vr_mgpu* m)
             // (s_render[] belong to the context)
             if (k.ev_render[b]) (void)hipEventDestroy(k.ev_render[b]);
             if (k.ev_gathered[b]) (void)hipEventDestroy(k.ev_gathered[b]);
+            for (hipEvent_t e : {k.tm_t0[b], k.tm_r[b], k.tm_g[b], k.tm_d[b]})
+                if (e) (void)hipEventDestroy(e);
+            if (k.present[b]) (void)hipFree(k.present[b]);
             if (k.tiles[b]) (void)hipFree(k.tiles[b]);
             if (k.gathered[b]) (void)hipFree(k.gathered[b]);
             if (k.frame[b]) (void)hipFree(k.frame[b]);
@@ -275,17 +295,23 @@ vr_ctx* vr_mgpu_context(vr_mgpu* m, int local_rank)
 const char* vr_mgpu_backend(const vr_mgpu* m) { return m ? m->backend.c_str() : ""; }
 
 // One launch per rank: n_frames frames (uniforms == nullptr: ONE frame with the uniforms set on each context).
-static int enqueue_frames(vr_mgpu* m, int variant, int n_frames, const vr_uniforms* uniforms)
+// A failure after the first rank's work has been enqueued leaves the ranks' streams out of step (some have the collective,
+// some do not): the handle is marked failed, an open group is closed, and every later call returns the stored error.
+static int enqueue_frames_impl(vr_mgpu* m, int variant, int n_frames, const vr_uniforms* uniforms, bool& group_open)
 {
     const int b = (int)(m->frame_no % (unsigned long long)m->slots);
     const int part_world = m->exp_share > 1 ? m->exp_share : m->world;
     const size_t seg = m->seg_floats ? m->seg_floats : 4;
+    for (auto& k : m->r)
+        if (!k.tiles[b] || (k.rank == 0 && (!k.gathered[b] || !k.frame[b] || !k.present[b])))
+            return fail(m, VR_ERR_NOT_READY, "vr_mgpu: buffer set not allocated (an earlier allocation failed)");
     // 1. every local rank renders its tiles into buffer set b, behind the gather that last read that tile buffer (not behind
-    //    the un-permute that followed it: that one reads the gather buffer and writes the frames, which only the
+    //    the output pass that followed it: that one reads the gather buffer and writes the frames, which only the
     //    communication stream touches, in order)
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
         if (k.used[b]) MG_HIP(m, hipStreamWaitEvent(k.s_render[b], k.ev_gathered[b], 0));
+        if (m->stage_timing) MG_HIP(m, hipEventRecord(k.tm_t0[b], k.s_render[b]));
         if (uniforms) {
             void* ptrs[kBatch];
             for (int f = 0; f < n_frames; ++f) ptrs[f] = k.tiles[b] + (size_t)f * seg;
@@ -293,33 +319,64 @@ static int enqueue_frames(vr_mgpu* m, int variant, int n_frames, const vr_unifor
         } else {
             MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, part_world, k.tiles[b], k.s_render[b]));
         }
+        if (m->stage_timing) MG_HIP(m, hipEventRecord(k.tm_r[b], k.s_render[b]));
         MG_HIP(m, hipEventRecord(k.ev_render[b], k.s_render[b]));
         MG_HIP(m, hipStreamWaitEvent(k.s_comm, k.ev_render[b], 0));
     }
     // 2. one gather: rank r's n_frames segments land back to back at gathered[b] + r * n_frames * seg on the root.  Every
     //    rank's communication stream carries the launches in the same order, so the collectives match up across ranks.
-    if (m->r.size() > 1) MG_NCCL(m, ncclGroupStart());
+    if (m->r.size() > 1) {
+        MG_NCCL(m, ncclGroupStart());
+        group_open = true;
+    }
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
         MG_NCCL(m, ncclGather(k.tiles[b], k.rank == 0 ? k.gathered[b] : nullptr, seg * (size_t)n_frames, ncclFloat, 0, k.comm, k.s_comm));
     }
-    if (m->r.size() > 1) MG_NCCL(m, ncclGroupEnd());
+    if (m->r.size() > 1) {
+        group_open = false;
+        MG_NCCL(m, ncclGroupEnd());
+    }
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
         MG_HIP(m, hipEventRecord(k.ev_gathered[b], k.s_comm));
+        if (m->stage_timing) MG_HIP(m, hipEventRecord(k.tm_g[b], k.s_comm));
     }
-    // 3. the root scatters the segments into the frames
+    // 3. the root turns the segments into what its consumer reads: the assembled float frames (un-permute: 16 B read + 16 B
+    //    written per pixel) and / or the presented BGRA8 frames straight from the tile-major segments (16 + 4 B per pixel,
+    //    the output merge of App/src/renderer/PipelineBuilder.cpp:142-154 reading through the permutation)
     const int tpr = (int)(seg / ((size_t)kTilePx * kTilePx * 4));
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
         if (k.rank == 0)
-            for (int f = 0; f < n_frames; ++f)
-                MG_VR(m, k, vr_unpack_tiles_strided_async(k.ctx, k.gathered[b] + (size_t)f * seg, part_world, n_frames * tpr,
-                                                          k.frame[b] + (size_t)f * m->W * m->H * 4, k.s_comm));
+            for (int f = 0; f < n_frames; ++f) {
+                if (m->output & VR_MGPU_OUT_FRAME)
+                    MG_VR(m, k, vr_unpack_tiles_strided_async(k.ctx, k.gathered[b] + (size_t)f * seg, part_world, n_frames * tpr,
+                                                              k.frame[b] + (size_t)f * m->W * m->H * 4, k.s_comm));
+                if (m->output & VR_MGPU_OUT_PRESENT)
+                    MG_VR(m, k, vr_present_tiles_async(k.ctx, k.gathered[b] + (size_t)f * seg, part_world, n_frames * tpr,
+                                                       k.present[b] + (size_t)f * m->W * m->H, k.s_comm));
+            }
+        if (m->stage_timing) {
+            MG_HIP(m, hipEventRecord(k.tm_d[b], k.s_comm));
+            k.tm_valid[b] = true;
+        }
         k.used[b] = true;
     }
     ++m->frame_no;
     return b;
+}
+
+static int enqueue_frames(vr_mgpu* m, int variant, int n_frames, const vr_uniforms* uniforms)
+{
+    if (m->failed) return VR_ERR_HIP;  // (m->err still holds what went wrong)
+    bool group_open = false;
+    const int rc = enqueue_frames_impl(m, variant, n_frames, uniforms, group_open);
+    if (rc < 0) {
+        if (group_open) (void)ncclGroupEnd();
+        if (rc != VR_ERR_NOT_READY || group_open) m->failed = true;
+    }
+    return rc;
 }
 
 int vr_mgpu_frame_async(vr_mgpu* m, int variant)
@@ -336,10 +393,17 @@ int vr_mgpu_frames_async(vr_mgpu* m, int variant, int n_frames, const vr_uniform
                                     // every rank is given the same n_frames)
         int rc = vr_mgpu_wait(m);
         if (rc != VR_OK) return rc;
-        m->batch_cap = n_frames;
+        const int old_cap = m->batch_cap;
+        m->batch_cap = n_frames;  // (alloc_buffers sizes the sets by it)
         for (auto& k : m->r) {
             rc = alloc_buffers(m, k);
-            if (rc != VR_OK) return rc;
+            if (rc != VR_OK) {
+                // some ranks have the new size, some have no buffers at all: enqueue_frames refuses null buffer sets, and the
+                // handle is poisoned so that no rank renders into a set of the wrong size
+                m->batch_cap = old_cap;
+                m->failed = true;
+                return rc;
+            }
         }
     }
     return enqueue_frames(m, variant, n_frames, uniforms);
@@ -387,6 +451,7 @@ int vr_mgpu_download(vr_mgpu* m, int which, float* frag_rgba) { return vr_mgpu_d
 int vr_mgpu_reduce(vr_mgpu* m, uint64_t counters_sum[3], double local_value, double* max_value)
 {
     if (!m) return VR_ERR_INVALID_ARG;
+    if (m->failed) return VR_ERR_HIP;
     int rc = vr_mgpu_wait(m);
     if (rc != VR_OK) return rc;
     for (auto& k : m->r) {
@@ -397,13 +462,30 @@ int vr_mgpu_reduce(vr_mgpu* m, uint64_t counters_sum[3], double local_value, dou
         MG_HIP(m, hipSetDevice(k.device));
         MG_HIP(m, hipMemcpy(k.d_red, h, sizeof h, hipMemcpyHostToDevice));
     }
-    if (m->r.size() > 1) MG_NCCL(m, ncclGroupStart());
-    for (auto& k : m->r) {
-        MG_HIP(m, hipSetDevice(k.device));
-        MG_NCCL(m, ncclAllReduce(k.d_red, k.d_red, 3, ncclUint64, ncclSum, k.comm, k.s_comm));
-        MG_NCCL(m, ncclAllReduce(k.d_red + 3, k.d_red + 3, 1, ncclFloat64, ncclMax, k.comm, k.s_comm));
+    {
+        // (a failure between group start and end must still close the group, and leaves the ranks out of step)
+        auto body = [&]() -> int {
+            for (auto& k : m->r) {
+                MG_HIP(m, hipSetDevice(k.device));
+                MG_NCCL(m, ncclAllReduce(k.d_red, k.d_red, 3, ncclUint64, ncclSum, k.comm, k.s_comm));
+                MG_NCCL(m, ncclAllReduce(k.d_red + 3, k.d_red + 3, 1, ncclFloat64, ncclMax, k.comm, k.s_comm));
+            }
+            return VR_OK;
+        };
+        if (m->r.size() > 1) MG_NCCL(m, ncclGroupStart());
+        const int brc = body();
+        if (m->r.size() > 1) {
+            const ncclResult_t er = ncclGroupEnd();
+            if (brc == VR_OK && er != ncclSuccess) {
+                m->failed = true;
+                return fail(m, VR_ERR_HIP, std::string("ncclGroupEnd: ") + ncclGetErrorString(er));
+            }
+        }
+        if (brc != VR_OK) {
+            m->failed = true;
+            return brc;
+        }
     }
-    if (m->r.size() > 1) MG_NCCL(m, ncclGroupEnd());
     Rank& k0 = m->r[0];
     MG_HIP(m, hipSetDevice(k0.device));
     MG_HIP(m, hipStreamSynchronize(k0.s_comm));
@@ -420,6 +502,78 @@ int vr_mgpu_reduce(vr_mgpu* m, uint64_t counters_sum[3], double local_value, dou
     }
     if (max_value) std::memcpy(max_value, &h[3], sizeof(double));
     return VR_OK;
+}
+
+int vr_mgpu_comm_count(const vr_mgpu* m)
+{
+    if (!m || m->r.empty() || !m->r[0].comm) return VR_ERR_INVALID_ARG;
+    int n = 0;
+    if (ncclCommCount(m->r[0].comm, &n) != ncclSuccess) return VR_ERR_HIP;
+    return n;
+}
+
+int vr_mgpu_device(const vr_mgpu* m, int local_rank)
+{
+    if (!m || local_rank < 0 || local_rank >= (int)m->r.size()) return VR_ERR_INVALID_ARG;
+    return m->r[(size_t)local_rank].device;
+}
+
+int vr_mgpu_set_output(vr_mgpu* m, int output)
+{
+    if (!m) return VR_ERR_INVALID_ARG;
+    if ((output & ~(VR_MGPU_OUT_FRAME | VR_MGPU_OUT_PRESENT)) != 0 || output == 0)
+        return fail(m, VR_ERR_INVALID_ARG, "vr_mgpu_set_output: VR_MGPU_OUT_FRAME and / or VR_MGPU_OUT_PRESENT");
+    m->output = output;
+    return VR_OK;
+}
+
+int vr_mgpu_set_stage_timing(vr_mgpu* m, int enabled)
+{
+    if (!m) return VR_ERR_INVALID_ARG;
+    int rc = vr_mgpu_wait(m);
+    if (rc != VR_OK) return rc;
+    m->stage_timing = enabled != 0;
+    for (auto& k : m->r)
+        for (int b = 0; b < kSlots; ++b) k.tm_valid[b] = false;
+    return VR_OK;
+}
+
+int vr_mgpu_stage_times(vr_mgpu* m, int local_rank, int which, float ms[4])
+{
+    if (!m || !ms || local_rank < 0 || local_rank >= (int)m->r.size() || which < 0 || which >= m->slots) return VR_ERR_INVALID_ARG;
+    Rank& k = m->r[(size_t)local_rank];
+    if (!k.tm_valid[which]) return fail(m, VR_ERR_NOT_READY, "vr_mgpu_stage_times: no timed launch in this buffer set");
+    MG_HIP(m, hipSetDevice(k.device));
+    MG_HIP(m, hipEventSynchronize(k.tm_d[which]));
+    MG_HIP(m, hipEventElapsedTime(&ms[0], k.tm_t0[which], k.tm_r[which]));
+    MG_HIP(m, hipEventElapsedTime(&ms[1], k.tm_r[which], k.tm_g[which]));
+    MG_HIP(m, hipEventElapsedTime(&ms[2], k.tm_g[which], k.tm_d[which]));
+    MG_HIP(m, hipEventElapsedTime(&ms[3], k.tm_t0[which], k.tm_d[which]));
+    return VR_OK;
+}
+
+void* vr_mgpu_present_device_ptr(vr_mgpu* m, int which, int frame_in_launch)
+{
+    if (!m || which < 0 || which >= m->slots || frame_in_launch < 0 || frame_in_launch >= m->batch_cap) return nullptr;
+    for (auto& k : m->r)
+        if (k.rank == 0) return k.present[which] + (size_t)frame_in_launch * m->W * m->H;
+    return nullptr;
+}
+
+int vr_mgpu_download_present(vr_mgpu* m, int which, int frame_in_launch, uint8_t* bgra8)
+{
+    if (!m || !bgra8 || which < 0 || which >= m->slots || frame_in_launch < 0 || frame_in_launch >= m->batch_cap)
+        return VR_ERR_INVALID_ARG;
+    int rc = vr_mgpu_wait(m);
+    if (rc != VR_OK) return rc;
+    for (auto& k : m->r)
+        if (k.rank == 0) {
+            MG_HIP(m, hipSetDevice(k.device));
+            MG_HIP(m, hipMemcpy(bgra8, k.present[which] + (size_t)frame_in_launch * m->W * m->H, (size_t)m->W * m->H * 4,
+                                hipMemcpyDeviceToHost));
+            return VR_OK;
+        }
+    return fail(m, VR_ERR_NOT_READY, "vr_mgpu_download_present: this process does not drive the root rank");
 }
 
 }  // extern "C"

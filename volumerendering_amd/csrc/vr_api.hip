@@ -1188,6 +1188,23 @@ int vr_present_async(vr_ctx* c, const void* d_frame, void* d_bgra8, void* stream
     return VR_OK;
 }
 
+int vr_present_tiles_async(vr_ctx* c, const void* d_gathered, int world, int rank_stride_tiles, void* d_bgra8, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!d_gathered || !d_bgra8 || world < 1) return fail(c, VR_ERR_INVALID_ARG, "vr_present_tiles_async: bad arguments");
+    const int tpr = tile_count(c, 0, world);
+    if (rank_stride_tiles <= 0) rank_stride_tiles = tpr;
+    if (rank_stride_tiles < tpr) return fail(c, VR_ERR_INVALID_ARG, "vr_present_tiles_async: stride smaller than a segment");
+    VR_HIP(c, hipSetDevice(c->device));
+    (void)hipGetLastError();
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    dim3 block(64, 4), grid((c->W + 63) / 64, (c->H + 3) / 4);
+    hipLaunchKernelGGL(present_tiles_kernel, grid, block, 0, s, (const float4*)d_gathered, (uint32_t*)d_bgra8, (int)c->W, (int)c->H,
+                       tiles_x_of(c), world, rank_stride_tiles);
+    VR_HIP(c, hipGetLastError());
+    return VR_OK;
+}
+
 int vr_download(vr_ctx* c, float* frag_rgba, uint8_t* present_bgra8, uint64_t* composited_samples)
 {
     if (!c) return VR_ERR_INVALID_ARG;

@@ -16,7 +16,11 @@ ID_BYTES = 128
 ABI_SYMBOLS = ["vr_mgpu_unique_id", "vr_mgpu_create", "vr_mgpu_create_local", "vr_mgpu_destroy", "vr_mgpu_last_error",
                "vr_mgpu_world", "vr_mgpu_local_ranks", "vr_mgpu_context", "vr_mgpu_frame_async", "vr_mgpu_wait",
                "vr_mgpu_frame_device_ptr", "vr_mgpu_download", "vr_mgpu_reduce", "vr_mgpu_backend", "vr_mgpu_frames_async",
-               "vr_mgpu_batch_frame_device_ptr", "vr_mgpu_download_batch_frame"]
+               "vr_mgpu_batch_frame_device_ptr", "vr_mgpu_download_batch_frame", "vr_mgpu_comm_count", "vr_mgpu_device",
+               "vr_mgpu_set_output", "vr_mgpu_present_device_ptr", "vr_mgpu_download_present", "vr_mgpu_set_stage_timing",
+               "vr_mgpu_stage_times"]
+
+OUT_FRAME, OUT_PRESENT = 1, 2
 
 _lib = None
 
@@ -50,6 +54,14 @@ def bind(path: str) -> C.CDLL:
     lib.vr_mgpu_reduce.argtypes = [vp, C.POINTER(C.c_uint64 * 3), C.c_double, C.POINTER(C.c_double)]
     lib.vr_mgpu_backend.argtypes = [vp]
     lib.vr_mgpu_backend.restype = C.c_char_p
+    lib.vr_mgpu_comm_count.argtypes = [vp]
+    lib.vr_mgpu_device.argtypes = [vp, i32]
+    lib.vr_mgpu_set_output.argtypes = [vp, i32]
+    lib.vr_mgpu_present_device_ptr.argtypes = [vp, i32, i32]
+    lib.vr_mgpu_present_device_ptr.restype = vp
+    lib.vr_mgpu_download_present.argtypes = [vp, i32, i32, vp]
+    lib.vr_mgpu_set_stage_timing.argtypes = [vp, i32]
+    lib.vr_mgpu_stage_times.argtypes = [vp, i32, i32, C.POINTER(C.c_float * 4)]
     return lib
 
 
@@ -150,6 +162,31 @@ class MultiGpu:
 
     def backend(self) -> str:
         return (self.lib.vr_mgpu_backend(self.h) or b"").decode()
+
+    def comm_count(self) -> int:
+        """ncclCommCount: the ranks RCCL itself sees in the communicator."""
+        return self._chk(self.lib.vr_mgpu_comm_count(self.h))
+
+    def device(self, local_rank: int = 0) -> int:
+        return self._chk(self.lib.vr_mgpu_device(self.h, local_rank))
+
+    def set_output(self, output: int):
+        """OUT_FRAME (assembled float frames), OUT_PRESENT (BGRA8 straight from the gathered tiles), or both."""
+        self._chk(self.lib.vr_mgpu_set_output(self.h, output))
+
+    def download_present(self, which: int, frame_in_launch: int, W: int, H: int) -> np.ndarray:
+        out = np.empty((H, W, 4), dtype=np.uint8)
+        self._chk(self.lib.vr_mgpu_download_present(self.h, which, frame_in_launch, out.ctypes.data))
+        return out
+
+    def set_stage_timing(self, enabled: bool):
+        self._chk(self.lib.vr_mgpu_set_stage_timing(self.h, 1 if enabled else 0))
+
+    def stage_times(self, local_rank: int, which: int):
+        """(march, gather, output, total) ms of the last launch into buffer set `which` on local rank `local_rank`."""
+        ms = (C.c_float * 4)()
+        self._chk(self.lib.vr_mgpu_stage_times(self.h, local_rank, which, C.byref(ms)))
+        return tuple(float(x) for x in ms)
 
 
 class BorrowedContext(capi.Context):
