@@ -313,7 +313,13 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *   6  one lane per ray (forced), 7  four lanes per ray (forced), 8  two lanes per ray (forced)
  *   9  one lane per ray with the next step's corner loads software-pipelined behind the shading
  *   10 / 11  four / two lanes per ray with the next round's corner loads software-pipelined (lit shader; what
- *      the default uses for small launches)                                                                  */
+ *      the default uses for small launches)
+ *   12 / 13  persistent wavefronts (csrc/vr_pw.h): one workgroup of 16 wavefronts per CU, the packets come from a queue
+ *      (eight heads, longest chains first), TF slot 0 is read from LDS; 13 also issues the next step's corner loads before
+ *      this step's shading (lit / unlit shader).  Launches of one frame; fewer bytes through the texture addressers
+ *   14  lanes per ray chosen PER PACKET (csrc/vr_mixed.h): packets whose longest ray chain in an earlier launch of the same
+ *      shape reached 75 % of that launch's longest are marched as two half packets with two lanes per ray, the rest with
+ *      one; one-frame launches of the shaders that have a depth-parallel form                                  */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 
 /* Arithmetic mode.  WGSL leaves it to the implementation whether `a * b + c` is evaluated with one rounding or two
@@ -343,6 +349,11 @@ int vr_volume_layout(vr_ctx* ctx, int slot, int* flags);
 
 /* The flavour the last render actually ran (what 0 resolved to for that launch), or a negative vr_status. */
 int vr_last_kernel_flavour(vr_ctx* ctx);
+
+/* Flavour 14 (lanes per ray chosen per packet): how many 8x8 packets the last launch marched as two half packets with two
+ * lanes per ray -- 0 until an item list of an earlier launch of the same shape exists (the fourth launch or so), or when the
+ * last launch was of another flavour.  Negative vr_status on error.                                                      */
+int vr_last_split_packets(vr_ctx* ctx);
 
 #ifdef __cplusplus
 }

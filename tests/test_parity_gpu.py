@@ -233,7 +233,7 @@ def test_skipping_with_hostile_values(ctx):
     tf = zero_prefix_tf(32, 3)
     for variant in (capi.BASIC, capi.LIGHT, capi.LIGHT_INSHADER):
         ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
-        for flavour in (0, 1, 5, 6, 8, 9, 11, 12, 13):  # every loop form and lanes-per-ray layout
+        for flavour in (0, 1, 5, 6, 8, 9, 11, 12, 13, 14):  # every loop form and lanes-per-ray layout
             ctx.set_kernel_flavour(flavour)
             frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
             assert same(frag, ref) and ns == n_ref, (variant, flavour)
@@ -405,7 +405,7 @@ def test_exact_leaping_flavour(ctx, flavour):
         ctx.set_kernel_flavour(0)
 
 
-@pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("variant", range(8))
 def test_every_variant_every_layout(ctx, variant, flavour):
     """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
@@ -672,7 +672,7 @@ def test_fused_every_variant_every_loop_form(fused, variant):
     W, H = 70, 45
     vols, tfs = vt.scene(variant, n=24)
     step, count = hr.stepping_params(24, 24, 24)
-    for fl in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+    for fl in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
         fused.set_kernel_flavour(fl)
         for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
                    dict(distance=0.7, yaw=1.0)):
@@ -1001,3 +1001,67 @@ def test_persistent_wavefronts_block_records(ctx):
     finally:
         ctx.set_kernel_flavour(0)
         ctx.resize(96, 80)
+
+
+# ---- lanes per ray chosen per packet (flavour 14, csrc/vr_mixed.h) -----------------------------------------------------------
+@pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.VOLUME_MASK, capi.THREE_FILES, capi.MULTI_CTRT, capi.TF_CALIB])
+def test_mixed_lanes_per_ray_per_packet(ctx, variant, monkeypatch):
+    """Flavour 14: from the fourth launch or so the packets with the longest chains are marched as two half packets with two
+    lanes per ray (an item list built behind an earlier launch), the others with one: every launch -- before and after the
+    list exists, with a moving camera that makes it stale -- is bit-equal to the oracle, the sample counts included, and the
+    per-packet records (summed over the two halves) equal the one-lane kernel's."""
+    W, H = 200, 150
+    vols, tfs = vt.scene(variant, n=32)
+    step, count = hr.stepping_params(32, 32, 32)
+    cams = [dict(yaw=0.6 + 0.01 * k) for k in range(8)] + [dict(yaw=2.0, pitch=-0.5, distance=0.9)] * 2 + [dict(clip_x=(0.2, 0.1))] * 4
+    monkeypatch.setenv("VR_EXP_SPLIT_MIN", "4")  # (the default floor of 64 samples: a 32^3 volume has no chain that long)
+    ctx = capi.Context(W, H)
+    try:
+        ctx.set_kernel_flavour(14)
+        split_seen = 0
+        for k, cam in enumerate(cams):
+            u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam)
+            check(ctx, variant, u, vols, tfs, W, H)
+            assert ctx.last_kernel_flavour() == 14
+            split_seen = max(split_seen, ctx.last_split_packets())
+        assert split_seen > 0  # the list came into use
+        # records: the mixed launch's (halves combined) against the one-lane kernel's, same camera
+        u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cams[-1])
+        recs = []
+        for fl in (14, 6):
+            ctx.set_kernel_flavour(fl)
+            for _ in range(6):
+                vt.gpu_render(ctx, variant, u, vols, tfs)
+            if fl == 14:
+                assert ctx.last_split_packets() > 0
+            recs.append(ctx.block_trace().astype(np.uint64))
+        a, b = recs
+        assert a.shape == b.shape and np.array_equal(a[:, :3], b[:, :3]) and np.array_equal(a[:, 5] >> 40, b[:, 5] >> 40)
+    finally:
+        ctx.close()
+
+
+def test_mixed_lanes_per_ray_at_1080p_and_every_threshold(ctx, monkeypatch):
+    """A 1080p frame (32 640 packets), packed tiles of a two-rank partition, and thresholds from 'split everything that samples'
+    to 'split nothing': always the one-lane kernel's frame and counts."""
+    W, H = 1920, 1080
+    vols, tfs = vt.scene(capi.LIGHT, n=24)
+    step, count = hr.stepping_params(24, 24, 24)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step, distance=0.9)
+    monkeypatch.setenv("VR_EXP_SPLIT_MIN", "4")
+    for pct in ("1", "50", "100", "1000"):
+        monkeypatch.setenv("VR_EXP_SPLIT_PCT", pct)
+        with capi.Context(W, H) as c2:
+            c2.set_kernel_flavour(6)
+            ref, _, n_ref = vt.gpu_render(c2, capi.LIGHT, u, vols, tfs)
+            c2.render_tiles(capi.LIGHT, 1, 2)
+            tiles_ref, nt_ref = c2.download_tiles(c2.tile_count(1, 2))
+            c2.set_kernel_flavour(14)
+            for k in range(7):
+                frag, _, n = vt.gpu_render(c2, capi.LIGHT, u, vols, tfs)
+                assert n == n_ref and np.array_equal(vt.bits(frag), vt.bits(ref)), (pct, k)
+            assert (c2.last_split_packets() > 0) == (pct != "1000")
+            for k in range(6):
+                c2.render_tiles(capi.LIGHT, 1, 2)
+                t, nt = c2.download_tiles(c2.tile_count(1, 2))
+                assert nt == nt_ref and np.array_equal(vt.bits(t), vt.bits(tiles_ref)), (pct, k)

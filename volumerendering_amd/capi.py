@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "vr_render_batch_async", "vr_render_tiles_batch_async", "vr_unpack_tiles_strided_async",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
     "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream", "vr_hint_frames_in_flight",
-    "vr_set_kernel_timing", "vr_present_tiles_async",
+    "vr_set_kernel_timing", "vr_present_tiles_async", "vr_last_split_packets",
 ]
 
 
@@ -112,6 +112,7 @@ def load() -> C.CDLL:
     lib.vr_last_block_trace.argtypes = [vp, C.c_void_p, C.c_int]
     lib.vr_set_kernel_flavour.argtypes = [vp, i32]
     lib.vr_last_kernel_flavour.argtypes = [vp]
+    lib.vr_last_split_packets.argtypes = [vp]
     lib.vr_set_volume_layout.argtypes = [vp, i32]
     lib.vr_set_arithmetic.argtypes = [vp, i32]
     lib.vr_present_async.argtypes = [vp, vp, vp, vp]
@@ -305,6 +306,10 @@ class Context:
 
     def frame_device_ptr(self) -> int:
         return int(self.lib.vr_frame_device_ptr(self.h) or 0)
+
+    def last_split_packets(self) -> int:
+        """Flavour 14: packets the last launch marched as two half packets with two lanes per ray."""
+        return self._chk(self.lib.vr_last_split_packets(self.h))
 
     def last_kernel_flavour(self) -> int:
         return self._chk(self.lib.vr_last_kernel_flavour(self.h))

@@ -14,6 +14,7 @@ void launch_march(const vr::LaunchDesc& L, hipStream_t s, const vr::MarchBatch& 
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace vr;
 
@@ -92,7 +93,15 @@ struct vr_ctx {
         unsigned long long key = 0, seq = 0;
         unsigned long long scene_key = 0;  // what the launch rendered, whatever kernel form it took (the chain length's key)
         bool valid = false;
+        unsigned* items = nullptr;  // mixed lanes per ray (vr_mixed.h): the item list built behind that launch's sort
+        size_t items_cap = 0;
+        bool has_items = false;
     } order_ring[kOrderRing];
+    unsigned* h_items = nullptr;  // pinned, one word per ring slot: grid of a launch that takes that slot's item list (0 = not built yet)
+    unsigned* h_split = nullptr;  // pinned: how many packets that list splits in two
+    int split_pct = 75;           // a packet is split when its longest chain reaches this share of the launch's longest (VR_EXP_SPLIT_PCT)
+    int split_min = 64;           // ... and at least this many samples (VR_EXP_SPLIT_MIN)
+    unsigned last_split = 0;      // packets the last mixed launch marched with two lanes per ray
     unsigned long long* h_span = nullptr;  // pinned, kRing words: duration of launch q in 100 MHz ticks + 1, from its records (0 = not known)
     bool ring_events[kRing] = {};          // launch q was timed with the events k0 / k1 instead (no sort behind it)
     unsigned* h_chain = nullptr;  // pinned, one word per ring slot: longest ray chain + 1 of that launch (0 = not known yet)
@@ -122,6 +131,11 @@ struct vr_ctx {
     bool last_otf = false;    // ... and whether it derived the gradients from the density plane
     int xcd_mode = 1;         // deal a tile's workgroups over the XCDs (VR_EXP_XCD=0: one XCD per tile)
     bool pw_ltf = true;       // persistent wavefronts keep TF slot 0 in LDS (VR_EXP_PW_LTF=0: from L1, for A/B)
+    bool pw_steal = false;    // ... and take other classes' packets once their own class is exhausted (VR_EXP_PW_STEAL=1: measured
+                              // 2-4 % slower -- the classes are even when a tile's packets are dealt over them)
+    double active_fraction = 1.0;  // share of bricks that are not inert, of the distance field in use
+    int pw_policy = 1;        // the default (flavour 0) may pick the persistent kernel (VR_EXP_PW_POLICY=0: never)
+    int pw_xcd_mode = -1;     // xcd_mode of persistent launches (VR_EXP_PW_XCD; -1 = the context's xcd_mode)
     std::string err;
 };
 
@@ -385,6 +399,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     }
     // persistent wavefronts (12; vr_pw.h) exist for launches of one frame
     if ((fl == 12 || fl == 13) && n_frames != 1) fl = 6;
+    // mixed lanes per ray (14; vr_mixed.h): launches of one frame, shaders that have a depth-parallel form
+    if (fl == 14 && (n_frames != 1 || variant == VR_VARIANT_ILLUSTRATIVE || variant == VR_VARIANT_LIGHT_INSHADER)) fl = 6;
     // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
     if (variant == VR_VARIANT_ILLUSTRATIVE && (fl == 7 || fl == 8 || fl == 10 || fl == 11)) fl = 6;
     // the in-shader gradient variant (seven density fetches per sample) exists as the one-lane kernel only
@@ -447,6 +463,16 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 hipLaunchKernelGGL(brick_dist_pass_kernel, g, b, 0, s, c->brick_dist, P.bnx, P.bny, P.bnz, k);
             hipLaunchKernelGGL(brick_dist_cap_kernel, g, b, 0, s, c->brick_dist, nb);
             VR_HIP(c, hipGetLastError());
+            {   // share of active bricks (steers the default kernel choice below)
+                unsigned* d_cnt = reinterpret_cast<unsigned*>(c->d_counters);
+                VR_HIP(c, hipMemsetAsync(d_cnt, 0, sizeof(unsigned), s));
+                hipLaunchKernelGGL(count_active_bricks_kernel, g, b, 0, s, c->brick_dist, nb, d_cnt);
+                VR_HIP(c, hipGetLastError());
+                unsigned cnt = 0;
+                VR_HIP(c, hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
+                VR_HIP(c, hipStreamSynchronize(s));
+                c->active_fraction = nb > 0 ? (double)cnt / (double)nb : 1.0;
+            }
             VR_HIP(c, hipStreamSynchronize(s));
             c->dist_records = (const void*)P.bricks;
             c->dist_epoch = c->brick_epoch;
@@ -455,6 +481,20 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             c->dist_rgb = P.use_rgb;
         }
         P.brick_dist = c->brick_dist;
+    }
+
+    // Default choice, second part: the persistent kernel (vr_pw.h: TF slot 0 in LDS, 4 wavefronts per SIMD, one launch at a time on
+    // the machine) where it measured faster than the one-lane kernel on whole frames -- volumes in which next to nothing can be
+    // skipped (noisy air under the default ramp: 3.62 -> 2.90 ms, the texture addressers lose the table texels) and the
+    // three-volume composite (C4: 0.68 -> 0.57 ms); it loses where most of the frame is skipped or thin (C2 0.10 -> 0.14, C5
+    // 3.35 -> 3.65, thin table 0.78 -> 0.85) and draws level on C3 (gpurun_out/r3b, r3d).
+    if (c->flavour == 0 && c->default_flavour == 0 && c->pw_policy && fl == 6 && n_frames == 1 && off32) {
+        const long long px_all = (long long)tile_count(c, rank, world) * kTile * kTile;
+        const bool whole_frame = (double)px_all / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 4.5;
+        const bool nothing_to_skip = !can_skip || c->active_fraction >= 0.9;
+        if (whole_frame && variant == VR_VARIANT_VOLUME_MASK) fl = 12;
+        else if (whole_frame && (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC) && nothing_to_skip) fl = 13;
+        c->last_flavour = fl;
     }
 
     if (packed && !out) {
@@ -491,6 +531,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // large launches, where 4x the workgroups cost more at dispatch than the finer order gains (C2: 32 768 workgroups of
         // a 0.12 ms frame)
         const bool pw = fl == 12 || fl == 13;
+        if (pw && c->pw_xcd_mode >= 0) P.xcd_mode = c->pw_xcd_mode;
         int wpb = wtb ? 4 : (pw ? 1 : c->waves_per_block);
         if (dp && P.n_tiles * (dp == 4 ? 256 : 128) > 16384) wpb = 4;
         dim3 block((unsigned)(64 * wpb));
@@ -506,7 +547,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             const vr_ctx::OrderSlot& po = c->order_ring[(c->order_seq - kInFlight) % kOrderRing];
             if (po.valid && po.seq + kInFlight == c->order_seq) VR_HIP(c, hipStreamWaitEvent(s, po.sorted, 0));
         }
-        const size_t n_records = (size_t)grid.x * (size_t)n_frames;  // every frame of the launch has its own records
+        // every frame of the launch has its own records; twice the space for one frame: a packet marched as two half packets
+        // (vr_mixed.h) leaves its second half's record grid.x records further on
+        const size_t n_records = (size_t)grid.x * (size_t)(n_frames > 1 ? n_frames : 2);
         if (n_records > c->block_counts_cap[cb]) {
             if (c->d_block_counts[cb]) (void)hipFree(c->d_block_counts[cb]);
             c->d_block_counts[cb] = nullptr;
@@ -527,6 +570,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                                         ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
                                         ((unsigned long long)fl << 44) ^ (packed ? 1ull << 63 : 0ull);
         P.order = nullptr;
+        const unsigned* mixed_items = nullptr;  // fl 14: the item list of an earlier launch of this shape, once one exists
+        unsigned mixed_grid = 0;
         const bool ordered = c->order_mode == 1 && !wtb && grid.x <= (unsigned)kOrderMaxBlocks && grid.x % 8u == 0;
         if (ordered) {
             const vr_ctx::OrderSlot* best = nullptr;
@@ -537,8 +582,18 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             if (best) {
                 VR_HIP(c, hipStreamWaitEvent(s, best->sorted, 0));
                 P.order = best->buf;
+                if (fl == 14 && best->has_items && c->h_items) {
+                    const int bi = (int)(best - c->order_ring);
+                    const unsigned n_pos = *(volatile unsigned*)&c->h_items[bi];
+                    if (n_pos >= grid.x && n_pos <= 2u * grid.x && n_pos % 8u == 0) {
+                        mixed_items = best->items;
+                        mixed_grid = n_pos;
+                        c->last_split = *(volatile unsigned*)&c->h_split[bi];
+                    }
+                }
             }
         }
+        if (!mixed_items) c->last_split = 0;
         const int slot = (int)(c->ring.head % kRing);
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
         // launches with a sort behind them are timed from their own records (order_blocks_kernel); events only otherwise
@@ -559,7 +614,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.pw_ltf = false;
             L.pw_pipe = false;
             L.lds_bytes = 0;
-            L.queue = PwQueue{nullptr, 0u};
+            L.queue = PwQueue{nullptr, 0u, 0u};
+            L.mixed_items = nullptr;
+            L.n_logical = 0;
             L.grid = grid;
             L.block = block;
             // frame f of the launch: every n_frames-th group of 8 workgroups (MarchBatch), its own uniforms, output and
@@ -588,10 +645,17 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 L.lds_bytes = L.pw_ltf ? (unsigned)(c->tf[0].res_o + 2) * 16u : 0u;
                 L.queue.heads = c->d_pw_heads + (size_t)cb * 8 * 64;
                 L.queue.n_items = grid.x;
+                L.queue.steal = c->pw_steal ? 1u : 0u;
                 L.grid = dim3(wgs < (unsigned)c->n_cus ? wgs : (unsigned)c->n_cus);
                 L.block = dim3(1024);
                 if (c->pw_heads_dirty[cb]) VR_HIP(c, hipMemsetAsync(L.queue.heads, 0, 8 * 64 * sizeof(unsigned), s));
                 c->pw_heads_dirty[cb] = !ordered;  // (an ordered launch's sort clears them behind it)
+            }
+            if (mixed_items) {
+                L.mixed_items = mixed_items;
+                L.n_logical = (int)grid.x;
+                L.grid = dim3(mixed_grid);
+                L.block = dim3(64);
             }
             if (c->arith == VR_ARITH_FUSED) vrf::launch_march(L, s, B);
             else vr::launch_march(L, s, B);
@@ -625,6 +689,23 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                                (c->h_span && !time_with_events) ? c->h_span + slot : (unsigned long long*)nullptr,
                                pw ? c->d_pw_heads + (size_t)cb * 8 * 64 : (unsigned*)nullptr);
             VR_HIP(c, hipGetLastError());
+            o.has_items = false;
+            if (fl == 14 && c->h_items && c->h_split) {
+                const int oi = (int)(c->order_seq % kOrderRing);
+                if (2 * (size_t)grid.x > o.items_cap) {
+                    if (o.items) (void)hipFree(o.items);
+                    o.items = nullptr;
+                    o.items_cap = 0;
+                    VR_HIP(c, hipMalloc(&o.items, 2 * (size_t)grid.x * sizeof(unsigned)));
+                    o.items_cap = 2 * (size_t)grid.x;
+                }
+                c->h_items[oi] = 0;
+                c->h_split[oi] = 0;
+                hipLaunchKernelGGL(build_items_kernel, dim3(1), dim3(1024), 0, c->order_stream, c->d_block_counts[cb], (int)grid.x, o.buf,
+                                   (unsigned)c->split_pct, (unsigned)c->split_min, o.items, c->h_items + oi, c->h_split + oi);
+                VR_HIP(c, hipGetLastError());
+                o.has_items = true;
+            }
             VR_HIP(c, hipEventRecord(o.sorted, c->order_stream));
             o.valid = true;
         }
@@ -877,6 +958,9 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_FLAVOUR")) c->default_flavour = atoi(e);
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
+    if (const char* e = getenv("VR_EXP_PW_STEAL")) c->pw_steal = atoi(e) != 0;
+    if (const char* e = getenv("VR_EXP_PW_POLICY")) c->pw_policy = atoi(e);
+    if (const char* e = getenv("VR_EXP_PW_XCD")) c->pw_xcd_mode = atoi(e);
     if (!hip_ok(hipMalloc(&c->d_pw_heads, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMalloc(queue heads)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipMemset(c->d_pw_heads, 0, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMemset(queue heads)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_begin), "hipEventCreate")) return bail(VR_ERR_HIP);
@@ -902,6 +986,14 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
         std::memset(c->h_span, 0, kRing * sizeof(unsigned long long));
     else
         c->h_span = nullptr;  // (every launch is then timed with events)
+    if (hipHostMalloc((void**)&c->h_items, 2 * kOrderRing * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) {
+        std::memset(c->h_items, 0, 2 * kOrderRing * sizeof(unsigned));
+        c->h_split = c->h_items + kOrderRing;
+    } else {
+        c->h_items = c->h_split = nullptr;  // (flavour 14 then always marches with one lane per ray)
+    }
+    if (const char* e = getenv("VR_EXP_SPLIT_PCT")) c->split_pct = atoi(e) > 0 ? atoi(e) : 75;
+    if (const char* e = getenv("VR_EXP_SPLIT_MIN")) c->split_min = atoi(e) > 0 ? atoi(e) : 64;
     if (hipHostMalloc((void**)&c->h_chain, kOrderRing * sizeof(unsigned), hipHostMallocDefault) == hipSuccess)
         std::memset(c->h_chain, 0, kOrderRing * sizeof(unsigned));
     else
@@ -966,8 +1058,10 @@ void vr_destroy(vr_ctx* c)
     for (auto& o : c->order_ring) {
         if (o.sorted) (void)hipEventDestroy(o.sorted);
         if (o.buf) (void)hipFree(o.buf);
+        if (o.items) (void)hipFree(o.items);
     }
     if (c->order_stream) (void)hipStreamDestroy(c->order_stream);
+    if (c->h_items) (void)hipHostFree(c->h_items);
     if (c->h_chain) (void)hipHostFree(c->h_chain);
     if (c->h_span) (void)hipHostFree(c->h_span);
     for (int k = 0; k < c->n_flight; ++k) (void)hipStreamDestroy(c->flight[k]);
@@ -1340,9 +1434,30 @@ int vr_last_block_trace(vr_ctx* c, uint64_t* out, int capacity)
     VR_HIP(c, hipSetDevice(c->device));
     VR_HIP(c, hipDeviceSynchronize());
     const int n = c->cnt_blocks < capacity ? c->cnt_blocks : capacity;
-    if (n > 0)
-        VR_HIP(c, hipMemcpy(out, c->d_block_counts[c->cnt_buf] + c->cnt_offset, (size_t)n * kBlockRecord * sizeof(unsigned long long),
-                            hipMemcpyDeviceToHost));
+    if (n > 0) {
+        const unsigned long long* src = c->d_block_counts[c->cnt_buf] + c->cnt_offset;
+        VR_HIP(c, hipMemcpy(out, src, (size_t)n * kBlockRecord * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        // packets marched as two half packets (vr_mixed.h): add the second half's record (cnt_offset == 0 for such launches)
+        bool any = false;
+        for (int i = 0; i < n && !any; ++i) any = (out[(size_t)i * kBlockRecord + 5] & kRecSplit) != 0;
+        if (any && c->cnt_offset == 0) {
+            std::vector<unsigned long long> second((size_t)n * kBlockRecord);
+            VR_HIP(c, hipMemcpy(second.data(), src + (size_t)c->cnt_blocks * kBlockRecord, second.size() * sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i) {
+                uint64_t* a = out + (size_t)i * kBlockRecord;
+                if (!(a[5] & kRecSplit)) continue;
+                const unsigned long long* b = second.data() + (size_t)i * kBlockRecord;
+                a[0] += b[0];
+                a[1] += b[1];
+                a[2] += b[2];
+                a[3] = b[3] < a[3] ? b[3] : a[3];
+                a[4] = b[4] > a[4] ? b[4] : a[4];
+                const unsigned long long ca = a[5] >> 40, cb2 = b[5] >> 40;
+                a[5] = (a[5] & ((1ull << 40) - 1)) | ((ca > cb2 ? ca : cb2) << 40);
+            }
+        }
+    }
     return c->cnt_blocks;
 }
 
@@ -1350,6 +1465,12 @@ int vr_last_kernel_flavour(vr_ctx* c)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     return c->last_flavour;
+}
+
+int vr_last_split_packets(vr_ctx* c)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    return (int)c->last_split;
 }
 
 // Event-timed span of one 150 us single-wavefront spin on a and, if b is given, a second one on b right behind it.
@@ -1456,7 +1577,7 @@ int vr_volume_layout(vr_ctx* c, int slot, int* flags)
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 13) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 14) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

@@ -10,6 +10,7 @@ constexpr int kTile = 64;        // multi-GPU ownership granule (pixels)
 constexpr int kBlockEdge = 16;   // one 256-thread workgroup = 16x16 pixels = four 8x8 wave packets
 constexpr int kBlockRecord = 6;  // u64 words per block in MarchParams::block_counts
 constexpr int kBlocksPerTile = (kTile / kBlockEdge) * (kTile / kBlockEdge);
+constexpr unsigned long long kRecSplit = 1ull << 39;  // record word 5: the packet was marched as two half packets (vr_mixed.h)
 // Empty-space bricks of 4 x 4 x 4 base cells (a brick's cells touch 5 x 5 x 5 voxels).  Round 1 used 8-cell bricks; 4-cell
 // ones leave 6.5 % fewer samples of C3 (39 % of C2) inside active bricks for a distance field 8 times the size (2 MB for
 // 512^3, 16 MB for 1024^3: one byte per brick) and are faster on every configuration (C3 0.573 -> 0.562 ms one frame at a
@@ -108,6 +109,7 @@ struct MarchBatch {
 struct PwQueue {
     unsigned* heads;
     unsigned n_items;  // logical blocks of the launch (a multiple of 8)
+    unsigned steal;    // 1: a wavefront whose class is exhausted takes items of the other classes
 };
 
 // What enqueue_render decided about one march launch; handed to launch_march of the arithmetic mode's translation unit
@@ -125,6 +127,8 @@ struct LaunchDesc {
     bool pw_pipe;     // ... with the next step's corner loads software-pipelined (lit / unlit shader)
     unsigned lds_bytes;
     PwQueue queue;
+    const unsigned* mixed_items;  // lanes per ray chosen per packet (vr_mixed.h): the item list, grid = its positions
+    int n_logical;                // ... and the logical blocks of the launch (where the second halves' records start)
     dim3 grid, block;
 };
 

@@ -91,15 +91,14 @@ __device__ __forceinline__ void dp_blend_slot(int flags, v2f s_rg, v2f s_ba, v2f
     alive = alive && !cut && !left;
 }
 
-template <int V, bool OFF32, bool SKIP, int K, bool PIPE, bool BATCH = false>
-__global__ __launch_bounds__(256) void march_dp_kernel(const MarchBatch B)
+// The whole depth-parallel march of the rays of one wavefront: lane = ray * K + depth slot, `slot` = the ray's pixel.  Shared by
+// march_dp_kernel and the mixed kernel (vr_mixed.h: two lanes per ray for the packets with the longest chains only).  Depth
+// slot 0 of every ray holds (like the others) the ray's result and counts on return.
+template <int V, bool OFF32, bool SKIP, int K, bool PIPE>
+__device__ __forceinline__ void march_dp_body(const MarchParams& P, const PixelSlot& slot, float4& dst, unsigned& blends,
+                                              unsigned& covered, unsigned& fetched)
 {
-    const MarchParams& P = frame_params<BATCH>(B);
-    const unsigned long long t_start = wall_clock64();
-    const PixelSlot slot = map_pixel_dp<K>(P);
     const int j = threadIdx.x & (K - 1);  // depth slot
-    float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    unsigned blends = 0, covered = 0, fetched = 0;
     bool alive = false;
     f3 p = mk3(0.0f, 0.0f, 0.0f), w = p, step = p, wstep = p;
     int n_inside = 0;
@@ -279,6 +278,18 @@ __global__ __launch_bounds__(256) void march_dp_kernel(const MarchBatch B)
     }
 
     if (P.fragment_mode < 1 || P.fragment_mode > 4) dst = make_float4(dxy.x, dxy.y, dzw.x, dzw.y);
+}
+
+template <int V, bool OFF32, bool SKIP, int K, bool PIPE, bool BATCH = false>
+__global__ __launch_bounds__(256) void march_dp_kernel(const MarchBatch B)
+{
+    const MarchParams& P = frame_params<BATCH>(B);
+    const unsigned long long t_start = wall_clock64();
+    const PixelSlot slot = map_pixel_dp<K>(P);
+    const int j = threadIdx.x & (K - 1);  // depth slot
+    float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    unsigned blends = 0, covered = 0, fetched = 0;
+    march_dp_body<V, OFF32, SKIP, K, PIPE>(P, slot, dst, blends, covered, fetched);
     // slot 0 of every ray holds (like the others) the ray's result and counts
     if (j == 0 && (slot.active || (P.packed && slot.in_launch))) P.out[slot.out_index] = dst;
     store_block_counts(P, j == 0 ? blends : 0u, j == 0 ? covered : 0u, j == 0 ? fetched : 0u, t_start);

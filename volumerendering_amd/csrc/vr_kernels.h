@@ -1174,7 +1174,36 @@ __device__ __forceinline__ void store_block_counts(const MarchParams& P, unsigne
         o[4] = wall_clock64();
         // HW_ID | XCC_ID << 32 | longest per-ray sample chain of the workgroup << 40
         o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
-               ((unsigned long long)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xffu) << 32) | (cr << 40);
+               ((unsigned long long)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0x7fu) << 32) | (cr << 40);  // (bit 39: kRecSplit)
+    }
+}
+
+// store_block_counts for a block of ONE wavefront that is not a workgroup (persistent wavefronts, vr_pw.h; mixed lanes per
+// ray, vr_mixed.h): no barrier, no LDS.  `rec` = the record's index; split = the packet's rays were marched by two
+// wavefronts (vr_mixed.h): this is the first half's record, the second half's is at rec + (logical blocks of the launch)
+// (kRecSplit in word 5 tells the readers -- sum_block_counts_kernel, order_blocks_kernel, vr_last_block_trace -- to add it).
+__device__ __forceinline__ void store_wave_counts(const MarchParams& P, int rec, unsigned blends, unsigned covered, unsigned fetched,
+                                                  unsigned long long t_start, bool split = false)
+{
+    unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
+    unsigned long long fetched_cnt = fetched;
+    unsigned crit = fetched;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        packed_cnt += __shfl_down(packed_cnt, off, 64);
+        fetched_cnt += __shfl_down(fetched_cnt, off, 64);
+        crit = max(crit, (unsigned)__shfl_down((int)crit, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* o = P.block_counts + (size_t)rec * kBlockRecord;
+        o[0] = packed_cnt & ((1ull << 40) - 1);
+        o[1] = packed_cnt >> 40;
+        o[2] = fetched_cnt;
+        o[3] = t_start;
+        o[4] = wall_clock64();
+        o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+               ((unsigned long long)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0x7fu) << 32) |
+               (split ? kRecSplit : 0ull) | ((unsigned long long)crit << 40);
     }
 }
 
@@ -1646,6 +1675,12 @@ __global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned lo
         a += in[(size_t)i * kBlockRecord];
         b += in[(size_t)i * kBlockRecord + 1];
         f += in[(size_t)i * kBlockRecord + 2];
+        if (in[(size_t)i * kBlockRecord + 5] & kRecSplit) {  // the packet's second half (vr_mixed.h)
+            const size_t h = (size_t)(i + n_blocks) * kBlockRecord;
+            a += in[h];
+            b += in[h + 1];
+            f += in[h + 2];
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1711,8 +1746,16 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
     for (int k = 0; k * 1024 < n_blocks; ++k) {
         const int b = t + k * 1024;
         if (b < n_blocks) {
-            const unsigned long long crit = in[(size_t)b * kBlockRecord + 5] >> 40;
-            const unsigned long long b0 = in[(size_t)b * kBlockRecord + 3], b1 = in[(size_t)b * kBlockRecord + 4];
+            const unsigned long long w5 = in[(size_t)b * kBlockRecord + 5];
+            unsigned long long crit = w5 >> 40;
+            unsigned long long b0 = in[(size_t)b * kBlockRecord + 3], b1 = in[(size_t)b * kBlockRecord + 4];
+            if (w5 & kRecSplit) {  // marched by two wavefronts (vr_mixed.h): the second half's record
+                const size_t h = (size_t)(b + n_blocks) * kBlockRecord;
+                const unsigned long long c2 = in[h + 5] >> 40, s2 = in[h + 3], e2 = in[h + 4];
+                crit = c2 > crit ? c2 : crit;
+                b0 = s2 < b0 ? s2 : b0;
+                b1 = e2 > b1 ? e2 : b1;
+            }
             my_first = b0 < my_first ? b0 : my_first;
             my_last = b1 > my_last ? b1 : my_last;
             my_chain = crit > my_chain ? (unsigned)crit : my_chain;
@@ -1796,6 +1839,15 @@ __global__ void brick_dist_cap_kernel(unsigned char* __restrict__ dist, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && dist[i] == 255) dist[i] = (unsigned char)kDistMax;
+}
+
+// how many bricks are active (distance 0): what share of the volume a frame can be expected to sample (the default kernel
+// choice of vr_api.hip: a volume with next to no inert bricks is marched by the persistent kernel)
+__global__ void count_active_bricks_kernel(const unsigned char* __restrict__ dist, int n, unsigned* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && dist[i] == 0);
+    if ((threadIdx.x & 63) == 0 && m != 0) atomicAdd(out, (unsigned)__popcll(m));
 }
 
 // VOLUME_MASK looks at two volumes on one grid: record = (max density of the CT, max(r,g,b) of the mask)

@@ -7,6 +7,7 @@
 #include "vr_kernels.h"
 #include "vr_dp.h"
 #include "vr_pw.h"
+#include "vr_mixed.h"
 #if !VR_FUSED
 #include "vr_wtb.h"
 #endif
@@ -116,9 +117,37 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 #undef VR_LAUNCH_PW
 }
 
+// lanes per ray per packet (vr_mixed.h)
+template <int V>
+void launch_mixed(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
+{
+    constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK);
+    if constexpr (kCanSkip) {
+        if (B.frame[0].brick_dist) {
+            if (L.off32) hipLaunchKernelGGL((march_mixed_kernel<V, true, true>), L.grid, L.block, 0, s, B, L.mixed_items, L.n_logical);
+            else hipLaunchKernelGGL((march_mixed_kernel<V, false, true>), L.grid, L.block, 0, s, B, L.mixed_items, L.n_logical);
+            return;
+        }
+    }
+    if (L.off32) hipLaunchKernelGGL((march_mixed_kernel<V, true, false>), L.grid, L.block, 0, s, B, L.mixed_items, L.n_logical);
+    else hipLaunchKernelGGL((march_mixed_kernel<V, false, false>), L.grid, L.block, 0, s, B, L.mixed_items, L.n_logical);
+}
+
 void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 {
     const int variant = L.variant;
+    if (L.mixed_items) {
+        switch (variant) {
+        case VR_VARIANT_BASIC: launch_mixed<V_BASIC>(L, s, B); break;
+        case VR_VARIANT_LIGHT: launch_mixed<V_LIGHT>(L, s, B); break;
+        case VR_VARIANT_VOLUME_MASK: launch_mixed<V_VOLUME_MASK>(L, s, B); break;
+        case VR_VARIANT_THREE_FILES: launch_mixed<V_THREE_FILES>(L, s, B); break;
+        case VR_VARIANT_MULTI_CTRT: launch_mixed<V_MULTI_CTRT>(L, s, B); break;
+        case VR_VARIANT_TF_CALIB: launch_mixed<V_TF_CALIB>(L, s, B); break;
+        default: break;  // (enqueue_render never asks: these shaders have no depth-parallel form)
+        }
+        return;
+    }
     if (L.pw) {
         switch (variant) {
         case VR_VARIANT_BASIC: launch_pw<V_BASIC>(L, s, B); break;

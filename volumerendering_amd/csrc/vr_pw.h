@@ -34,32 +34,6 @@ using namespace vr;
 constexpr int kPwThreads = 1024;      // one workgroup per CU: 16 wavefronts, 4 per SIMD (<= 128 VGPRs each)
 constexpr int kPwHeadStride = 64;     // the eight heads are 256 B apart (a memory channel each)
 
-// store_block_counts for a block of ONE wavefront that is not a workgroup: no barrier, no LDS
-__device__ __forceinline__ void store_wave_counts(const MarchParams& P, int lb, unsigned blends, unsigned covered, unsigned fetched,
-                                                  unsigned long long t_start)
-{
-    unsigned long long packed_cnt = ((unsigned long long)covered << 40) | (unsigned long long)blends;
-    unsigned long long fetched_cnt = fetched;
-    unsigned crit = fetched;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        packed_cnt += __shfl_down(packed_cnt, off, 64);
-        fetched_cnt += __shfl_down(fetched_cnt, off, 64);
-        crit = max(crit, (unsigned)__shfl_down((int)crit, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long* o = P.block_counts + (size_t)lb * kBlockRecord;
-        o[0] = packed_cnt & ((1ull << 40) - 1);
-        o[1] = packed_cnt >> 40;
-        o[2] = fetched_cnt;
-        o[3] = t_start;
-        o[4] = wall_clock64();
-        o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
-               ((unsigned long long)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xffu) << 32) |
-               ((unsigned long long)crit << 40);
-    }
-}
-
 // PIPE (lit and unlit shader): the next step's eight corner loads are issued before this step's shading (march_packet's
 // software-pipelined loop form): with the table texels coming from LDS the corner fetch is the one memory round trip left
 // in a step, and it then overlaps the arithmetic of the step before.
@@ -81,11 +55,25 @@ __global__ __launch_bounds__(kPwThreads) void march_pw_kernel(const MarchBatch B
     const unsigned wib = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned wpb = kPwThreads / 64;
     const unsigned n_c = Q.n_items >> 3;                  // items per class (n_items is a multiple of 8)
-    const unsigned waves_c = groups * wpb;
     // first item: static, wavefront k of every workgroup before wavefront k + 1 of any (the order is longest first)
     unsigned idx = wib * groups + (blockIdx.x >> 3);
-    while (idx < n_c) {
-        const unsigned pos = (idx << 3) | cls;
+    // A wavefront whose class has run dry goes on with the next class's queue (Q.steal; a class is an XCD's share of the
+    // packets: with whole tiles per class -- xcd_mode 0: the 64 packets of a tile share an L2 -- the classes' work differs by a
+    // factor of 1.5, which stealing evens out at the end of the launch).  Every item is still handed out exactly once: item
+    // index = the head's old value + the number of that class's static items.
+    unsigned cur = cls, tried = 0;
+    for (;;) {
+        if (idx >= n_c) {
+            if (!Q.steal || ++tried >= 8u) break;
+            cur = (cur + 1u) & 7u;
+            const unsigned groups_o = (gridDim.x - cur + 7u) >> 3;
+            unsigned r = 0;
+            if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
+            idx = groups_o * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+            continue;
+        }
+        tried = 0;
+        const unsigned pos = (idx << 3) | cur;
         int lb = (int)pos;
         if (P.order != nullptr) lb = __builtin_amdgcn_readfirstlane((int)P.order[pos]);
         const unsigned long long t_start = wall_clock64();
@@ -96,8 +84,9 @@ __global__ __launch_bounds__(kPwThreads) void march_pw_kernel(const MarchBatch B
         if (slot.active || (P.packed && slot.in_launch)) P.out[slot.out_index] = dst;
         store_wave_counts(P, lb, blends, covered, fetched, t_start);
         unsigned r = 0;
-        if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cls * kPwHeadStride, 1u);
-        idx = waves_c + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+        if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
+        const unsigned groups_cur = (gridDim.x - cur + 7u) >> 3;
+        idx = groups_cur * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
     }
 }
 
