@@ -366,9 +366,9 @@ def main():
     ap.add_argument("--flavour", type=int, default=0)
     ap.add_argument("--arith", default="separate", choices=["separate", "fused"],
                     help="vr_set_arithmetic for the headline legs (the other mode is timed as the `arith_ab` leg)")
-    ap.add_argument("--layout", type=int, default=0, choices=[0, 1, 2],
-                    help="vr_set_volume_layout: 0 density plane for .a fetches, 1 the reference's vec4 voxels only, 2 = 0 + lit "
-                         "gradients derived on the fly from the plane")
+    ap.add_argument("--layout", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="vr_set_volume_layout: 0 bricked copy of voxels + density plane (default), 3 x-fastest voxels + plane (round 2's "
+                         "default), 1 the reference's vec4 voxels only, 2 = 3 + lit gradients derived on the fly from the plane")
     ap.add_argument("--vol-n", type=int, default=0, help="experiment: smaller volume, same frame and stepping")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="launches in flight in the pipelined / batched legs")
@@ -866,8 +866,10 @@ def main():
             "composited_samples_frame0": total_samples, "fetched_samples_frame0": total_fetched, "covered_pixels_frame0": covered,
             "composited_samples_per_frame_min_max": [min(c[0] for c in counts), max(c[0] for c in counts)],
             "kernel_flavour": args.flavour, "kernel_flavour_resolved": ran,
-            "volume_layout": ("density plane for .a fetches" + (", corner gradients derived on the fly" if layout_flags & 4 else ""))
-                             if args.layout != 1 else "reference vec4 voxels only",
+            "volume_layout": {0: "bricked copy (4 x 4 x 4 voxel bricks, brick-linear) of the vec4 voxels + density plane",
+                              1: "reference vec4 voxels only, x fastest",
+                              2: "x-fastest density plane, corner gradients derived on the fly" if layout_flags & 4 else "x-fastest vec4 voxels + density plane",
+                              3: "x-fastest vec4 voxels + density plane (round 2's default)"}[args.layout],
         },
         "serial": serial, "overlapped": over, "roofline": roofline,
     }

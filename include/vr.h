@@ -335,15 +335,20 @@ int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 int vr_set_arithmetic(vr_ctx* ctx, int mode);
 
 /* Volume layout in HBM (A/B measurements; frames and counts are bit-identical in every mode).
- *   0  default: next to the reference's vec4 voxels every slot keeps a scalar f32 density plane (4 B / voxel); fetches
- *      that consume .a alone (BasicVolumeApp.wgsl:171 and the density / dose fetches of the other shaders) read it
+ *   0  default: the march kernels gather from a BRICKED copy of every slot -- the vec4 voxels and a scalar f32 density plane
+ *      (what fetches that consume .a alone read: BasicVolumeApp.wgsl:171, the density / dose fetches of the other shaders)
+ *      in bricks of 4 x 4 x 4 voxels, brick after brick: 1 KiB per brick, a 128-byte line = 4 x 2 x 1 voxels, so that the
+ *      lines a packet of rays needs next are near the ones it has whatever direction it travels in.  The reference's
+ *      x-fastest array (App/src/file/VolumeFile.cpp:287-307: what vr_volume_upload takes, the data-preparation calls work on
+ *      and vr_volume_download returns) stays resident beside it; the copy is rebuilt after every upload / in-place change
+ *   3  round 2's default: the reference's x-fastest vec4 voxels + an x-fastest density plane
  *   1  the reference's RGBA32F voxels only (16 B / voxel; what round 1 measured)
  *   2  0 + the lit shader derives the eight corner gradients from the plane on the fly when the slot's .rgb is verified,
  *      at upload, to be VolumeFile::PreComputeGradient(false) of its .a bit for bit (VolumeFile.cpp:196-257): a quarter of
  *      the footprint and 0.69x the fabric traffic, but 1.5x the L1 accesses of the row-major plane -- measured slower
  *      (DESIGN.md section 4.5), kept for A/B
  * vr_volume_layout: *flags bit 0 = density plane present, bit 1 = .rgb verified as the central difference of .a,
- * bit 2 = the last render derived its gradients on the fly.                                                    */
+ * bit 2 = the last render derived its gradients on the fly, bit 3 = the bricked copy is what the gathers read.  */
 int vr_set_volume_layout(vr_ctx* ctx, int mode);
 int vr_volume_layout(vr_ctx* ctx, int slot, int* flags);
 

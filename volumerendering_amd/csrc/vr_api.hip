@@ -49,6 +49,9 @@ struct vr_ctx {
     float2* vol_bricks[VR_MAX_VOLUMES] = {};  // per brick: (max density, max(r,g,b)) -- empty-space skipping
     float* vol_dens[VR_MAX_VOLUMES] = {};     // scalar density plane of each slot (DevVolume::dens)
     size_t vol_dens_cap[VR_MAX_VOLUMES] = {};  // in voxels
+    float4* vol_bricked[VR_MAX_VOLUMES] = {};  // the voxels again in 4 x 4 x 4 bricks (DevVolume::bricked), what the march kernels gather from
+    float* vol_bdens[VR_MAX_VOLUMES] = {};     // ... and their density plane in the same order
+    size_t vol_bricked_cap[VR_MAX_VOLUMES] = {};  // in slots (bricks x 64)
     bool vol_grad_derived[VR_MAX_VOLUMES] = {};  // .rgb verified to be PreComputeGradient(false) of .a, bit for bit
     int arith = VR_ARITH_SEPARATE;             // vr_set_arithmetic
     int layout_mode = 0;                       // vr_set_volume_layout: 0 density plane for .a fetches, 1 vec4 voxels only,
@@ -345,7 +348,28 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         P.vol[i].dens = plane ? c->vol_dens[i] : nullptr;
         P.vol[i].a_base = plane ? reinterpret_cast<const char*>(c->vol_dens[i]) : reinterpret_cast<const char*>(c->vol[i].data) + 12;
         P.vol[i].a_shift = plane ? 2 : 4;
+        P.vol[i].bricked = 0;
+        P.vol[i].brick_row = P.vol[i].brick_slab = 0;
+        const size_t lin_bytes = c->vol_bytes[i];
+        P.vol[i].data_bytes = lin_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)lin_bytes;
     }
+    // the bricked copies (layout 0) are what the gathers read; decided below, once the kernel form is known (the LDS wave-tile
+    // flavours and the on-the-fly gradients address the reference's x-fastest order)
+    auto use_bricked = [&]() {
+        for (int i = 0; i < VR_MAX_VOLUMES; ++i) {
+            if (!c->vol[i].data || !c->vol_bricked[i] || !c->vol_bdens[i]) continue;
+            const unsigned nbx = ((unsigned)c->vol[i].nx + 3u) >> 2, nby = ((unsigned)c->vol[i].ny + 3u) >> 2, nbz = ((unsigned)c->vol[i].nz + 3u) >> 2;
+            const size_t slots = (size_t)nbx * nby * nbz * 64;
+            if (slots > 0xFFFFFFFFull) continue;  // (indices are 32 bits)
+            P.vol[i].data = c->vol_bricked[i];
+            P.vol[i].a_base = reinterpret_cast<const char*>(c->vol_bdens[i]);
+            P.vol[i].a_shift = 2;
+            P.vol[i].bricked = 1;
+            P.vol[i].brick_row = nbx * 64u;
+            P.vol[i].brick_slab = nbx * nby * 64u;
+            P.vol[i].data_bytes = slots * 16 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)(slots * 16);
+        }
+    };
     for (int i = 0; i < VR_MAX_TFS; ++i) P.tf[i] = c->tf[i];
     P.rank = rank;
     P.world = world;
@@ -496,6 +520,10 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         else if (whole_frame && (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC) && nothing_to_skip) fl = 13;
         c->last_flavour = fl;
     }
+
+    if (c->layout_mode == 0 && fl != 2 && fl != 3) use_bricked();
+    for (int i = 0; i < nvol; ++i)  // (a bricked copy is padded to whole bricks: a volume just below 4 GiB may cross the line)
+        if (P.vol[i].bricked && (size_t)P.vol[i].brick_slab * (((unsigned)P.vol[i].nz + 3u) >> 2) * 16 > 0xFFFFFFFFull) off32 = false;
 
     if (packed && !out) {
         size_t need = (size_t)P.n_tiles * kTile * kTile;
@@ -791,6 +819,24 @@ int refresh_bricks(vr_ctx* c, int slot)
     VR_HIP(c, hipStreamSynchronize(c->stream));
     c->vol_grad_derived[slot] = flag == 0;
     c->vol[slot].dens = c->vol_dens[slot];
+    {   // the bricked copy the march kernels gather from (DevVolume::bricked)
+        const unsigned nbx = ((unsigned)v.nx + 3u) >> 2, nby = ((unsigned)v.ny + 3u) >> 2, nbz = ((unsigned)v.nz + 3u) >> 2;
+        const size_t slots = (size_t)nbx * nby * nbz * 64;
+        if (slots > c->vol_bricked_cap[slot]) {
+            if (c->vol_bricked[slot]) (void)hipFree(c->vol_bricked[slot]);
+            if (c->vol_bdens[slot]) (void)hipFree(c->vol_bdens[slot]);
+            c->vol_bricked[slot] = nullptr;
+            c->vol_bdens[slot] = nullptr;
+            c->vol_bricked_cap[slot] = 0;
+            VR_HIP(c, hipMalloc(&c->vol_bricked[slot], slots * sizeof(float4)));
+            VR_HIP(c, hipMalloc(&c->vol_bdens[slot], slots * sizeof(float)));
+            c->vol_bricked_cap[slot] = slots;
+        }
+        hipLaunchKernelGGL(rebrick_kernel, dim3(8192), dim3(256), 0, c->stream, v.data, c->vol_bricked[slot], c->vol_bdens[slot], v.nx,
+                           v.ny, v.nz, nbx, nby, slots);
+        VR_HIP(c, hipGetLastError());
+        VR_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return VR_OK;
 }
 
@@ -1033,8 +1079,11 @@ void vr_destroy(vr_ctx* c)
         if (c->vol[i].data) (void)hipFree(const_cast<float4*>(c->vol[i].data));
     for (int i = 0; i < VR_MAX_VOLUMES; ++i)
         if (c->vol_bricks[i]) (void)hipFree(c->vol_bricks[i]);
-    for (int i = 0; i < VR_MAX_VOLUMES; ++i)
+    for (int i = 0; i < VR_MAX_VOLUMES; ++i) {
         if (c->vol_dens[i]) (void)hipFree(c->vol_dens[i]);
+        if (c->vol_bricked[i]) (void)hipFree(c->vol_bricked[i]);
+        if (c->vol_bdens[i]) (void)hipFree(c->vol_bdens[i]);
+    }
     if (c->merged_bricks) (void)hipFree(c->merged_bricks);
     if (c->brick_dist) (void)hipFree(c->brick_dist);
     for (int i = 0; i < VR_MAX_TFS; ++i) {
@@ -1560,7 +1609,7 @@ int vr_set_arithmetic(vr_ctx* c, int mode)
 int vr_set_volume_layout(vr_ctx* c, int mode)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (mode < 0 || mode > 2) return fail(c, VR_ERR_INVALID_ARG, "vr_set_volume_layout: unknown mode");
+    if (mode < 0 || mode > 3) return fail(c, VR_ERR_INVALID_ARG, "vr_set_volume_layout: unknown mode");
     c->layout_mode = mode;
     return VR_OK;
 }
@@ -1570,7 +1619,8 @@ int vr_volume_layout(vr_ctx* c, int slot, int* flags)
     if (!c || !flags) return VR_ERR_INVALID_ARG;
     if (slot < 0 || slot >= VR_MAX_VOLUMES) return fail(c, VR_ERR_INVALID_ARG, "vr_volume_layout: bad slot");
     if (!c->vol[slot].data) return fail(c, VR_ERR_NOT_READY, "vr_volume_layout: volume slot is empty");
-    *flags = (c->vol_dens[slot] ? 1 : 0) | (c->vol_grad_derived[slot] ? 2 : 0) | (c->last_otf ? 4 : 0);
+    *flags = (c->vol_dens[slot] ? 1 : 0) | (c->vol_grad_derived[slot] ? 2 : 0) | (c->last_otf ? 4 : 0) |
+             ((c->vol_bricked[slot] && c->layout_mode == 0) ? 8 : 0);
     return VR_OK;
 }
 

@@ -36,6 +36,17 @@ struct DevVolume {
     const char* a_base;
     int a_shift;
     int nx, ny, nz;
+    // Bricked layout (default, vr_set_volume_layout(0)): `data` and the density plane behind `a_base` hold the voxels
+    // in bricks of 4 x 4 x 4, brick after brick (x fastest), the 64 voxels of a brick in x-fastest order: voxel (x, y, z) lives at
+    //     (x >> 2) * 64 + (x & 3)  +  (y >> 2) * brick_row + (y & 3) * 4  +  (z >> 2) * brick_slab + (z & 3) * 16
+    // -- a sum of one term per axis, so the eight corners of a cell are sums of two terms per axis.  A 1 KiB brick is eight
+    // 128-byte lines of 4 x 2 x 1 voxels: the 7 x 7 x 2 voxel patch a packet's corner load touches spans ~20 lines instead of
+    // the ~30 of the reference's x-fastest rows, and the lines a ray needs next lie in the same or the neighbouring brick
+    // whatever direction it travels in (with x-fastest rows a ray along z changes its 4 MiB slice every step).  bricked == 0:
+    // the reference's order (VolumeFile.cpp:306), idx = (z * ny + y) * nx + x.
+    int bricked;
+    unsigned brick_row, brick_slab;  // voxels per row of bricks (ceil(nx / 4) * 64) and per slab of bricks (* ceil(ny / 4))
+    unsigned data_bytes;             // size of `data` (the range of the kernels' buffer loads; volumes below 4 GiB)
 };
 
 // Both tables are stored with their first and their last texel repeated once at either end: table[k] is at [k+1].

@@ -249,6 +249,25 @@ __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
     const unsigned row = (unsigned)v.nx, slab = (unsigned)v.nx * (unsigned)v.ny;
     const int tx = (int)x0, ty = (int)y0, tz = (int)z0;  // saturating conversions, NaN -> 0
     const bool inner = (unsigned)tx < (unsigned)(v.nx - 1) && (unsigned)ty < (unsigned)(v.ny - 1) && (unsigned)tz < (unsigned)(v.nz - 1);
+    if (v.bricked) {  // (wave-uniform) bricks of 4 x 4 x 4: the index is a sum of one term per axis (DevVolume)
+        int i0 = tx, j0 = ty, k0 = tz, i1 = tx + 1, j1 = ty + 1, k1 = tz + 1;
+        if (__ballot(!inner) != 0) {  // some ray's cell touches a face: the clamp-to-edge texel pairs
+            texel_pair(x0, v.nx, i0, i1);
+            texel_pair(y0, v.ny, j0, j1);
+            texel_pair(z0, v.nz, k0, k1);
+        }
+        const unsigned ax0 = ((unsigned)i0 >> 2) * 64u + ((unsigned)i0 & 3u), ax1 = ((unsigned)i1 >> 2) * 64u + ((unsigned)i1 & 3u);
+        const unsigned ay0 = ((unsigned)j0 >> 2) * v.brick_row + (((unsigned)j0 & 3u) << 2);
+        const unsigned ay1 = ((unsigned)j1 >> 2) * v.brick_row + (((unsigned)j1 & 3u) << 2);
+        const unsigned az0 = ((unsigned)k0 >> 2) * v.brick_slab + (((unsigned)k0 & 3u) << 4);
+        const unsigned az1 = ((unsigned)k1 >> 2) * v.brick_slab + (((unsigned)k1 & 3u) << 4);
+        const unsigned r00 = ay0 + az0, r10 = ay1 + az0, r01 = ay0 + az1, r11 = ay1 + az1;
+        c.o000 = r00 + ax0; c.o100 = r00 + ax1;
+        c.o010 = r10 + ax0; c.o110 = r10 + ax1;
+        c.o001 = r01 + ax0; c.o101 = r01 + ax1;
+        c.o011 = r11 + ax0; c.o111 = r11 + ax1;
+        return c;
+    }
     if (__ballot(!inner) == 0) {
         // every ray of the packet that samples now has its cell strictly inside the volume: nothing to clamp
         c.o000 = ((unsigned)tz * (unsigned)v.ny + (unsigned)ty) * row + (unsigned)tx;
@@ -304,8 +323,7 @@ __device__ __forceinline__ float4 load_voxel(const DevVolume& v, unsigned idx)
 {
 #if VR_BUFFER_LOADS
     if constexpr (OFF32) {
-        const unsigned bytes = ((unsigned)v.nx * (unsigned)v.ny * (unsigned)v.nz) << 4;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(v.data), 0, (int)bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(v.data), 0, (int)v.data_bytes, 0x00020000);
         const vr_f4 f = __builtin_bit_cast(vr_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx << 4), 0, 0));
         return make_float4(f.x, f.y, f.z, f.w);
     }
@@ -547,6 +565,9 @@ __device__ __forceinline__ float4 tex3_nearest(const DevVolume& v, f3 p)
     int j = clampi((int)floorf(p.y * (float)v.ny), 0, v.ny - 1);
     int k = clampi((int)floorf(p.z * (float)v.nz), 0, v.nz - 1);
     unsigned idx = ((unsigned)k * (unsigned)v.ny + (unsigned)j) * (unsigned)v.nx + (unsigned)i;
+    if (v.bricked)
+        idx = ((unsigned)i >> 2) * 64u + ((unsigned)i & 3u) + ((unsigned)j >> 2) * v.brick_row + (((unsigned)j & 3u) << 2) +
+              ((unsigned)k >> 2) * v.brick_slab + (((unsigned)k & 3u) << 4);
     return load_vec4<OFF32>(v.data, idx);
 }
 
@@ -1856,6 +1877,26 @@ __global__ void merge_bricks_kernel(const float2* __restrict__ density_vol, cons
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = make_float2(density_vol[i].x, mask_vol[i].y);
+}
+
+// ---- bricked copy of a volume (DevVolume::bricked; rebuilt with the brick records after every upload or in-place change) -----
+// One thread per slot of the bricked arrays: slot s = brick * 64 + (lz * 16 + ly * 4 + lx); voxels beyond the volume's faces
+// (the last brick of an axis whose size is not a multiple of 4) are zero and never addressed.
+__global__ void rebrick_kernel(const float4* __restrict__ lin, float4* __restrict__ bvol, float* __restrict__ bdens, int nx, int ny,
+                               int nz, unsigned nbx, unsigned nby, size_t n_slots)
+{
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; s < n_slots; s += stride) {
+        const unsigned l = (unsigned)(s & 63u);
+        const size_t b = s >> 6;
+        const unsigned bx = (unsigned)(b % nbx), by = (unsigned)((b / nbx) % nby), bz = (unsigned)(b / ((size_t)nbx * nby));
+        const int x = (int)(bx * 4u + (l & 3u)), y = (int)(by * 4u + ((l >> 2) & 3u)), z = (int)(bz * 4u + (l >> 4));
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (x < nx && y < ny && z < nz) v = lin[((size_t)z * ny + y) * nx + x];
+        bvol[s] = v;
+        bdens[s] = v.w;
+    }
 }
 
 // ---- density plane / derived-gradient check (run with the brick records after every upload or in-place change) -------
