@@ -233,7 +233,7 @@ def test_skipping_with_hostile_values(ctx):
     tf = zero_prefix_tf(32, 3)
     for variant in (capi.BASIC, capi.LIGHT, capi.LIGHT_INSHADER):
         ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
-        for flavour in (0, 1, 5, 6, 8, 9, 11, 12, 13, 14):  # every loop form and lanes-per-ray layout
+        for flavour in (0, 1, 5, 6, 8, 9, 11, 12, 13, 14, 15):  # every loop form and lanes-per-ray layout
             ctx.set_kernel_flavour(flavour)
             frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
             assert same(frag, ref) and ns == n_ref, (variant, flavour)
@@ -248,7 +248,7 @@ def test_skipping_with_hostile_values(ctx):
         for variant in (capi.BASIC, capi.LIGHT):
             ref, n_ref, _ = ob.render(variant, u, [lone], [tf], W, H, nthreads=8)
             assert np.isnan(ref).any()
-            for flavour in (0, 6, 11, 12, 13):
+            for flavour in (0, 6, 11, 12, 13, 15):
                 ctx.set_kernel_flavour(flavour)
                 frag, _, ns = vt.gpu_render(ctx, variant, u, [lone], [tf])
                 assert same(frag, ref) and ns == n_ref, (bad, where, variant, flavour)
@@ -367,7 +367,7 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
                 assert ctx.counters()[2] < 0.5 * ns
 
 
-@pytest.mark.parametrize("flavour", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("flavour", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15])
 def test_exact_leaping_flavour(ctx, flavour):
     """Every way of getting through empty space and every lanes-per-ray layout must reproduce the step-by-step
     accumulation bit for bit (frames AND sample counts): 5 single steps, 6 wave-uniform runs of plain additions,
@@ -392,7 +392,7 @@ def test_exact_leaping_flavour(ctx, flavour):
                 kw.update(extra)
                 u = hr.make_uniforms(W, H, **kw)
                 for variant in (capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.LIGHT_INSHADER):
-                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6, 12, 13):
+                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6, 12, 13, 15):
                         continue  # one-lane kernel only: the other flavours resolve to 6
                     vols = [v] if variant != capi.THREE_FILES else [v, vt.dose_volume()]
                     tfs = [tf] if variant != capi.THREE_FILES else [tf, vt.scene(capi.THREE_FILES, n=8)[1][1]]
@@ -405,7 +405,7 @@ def test_exact_leaping_flavour(ctx, flavour):
         ctx.set_kernel_flavour(0)
 
 
-@pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 @pytest.mark.parametrize("variant", range(8))
 def test_every_variant_every_layout(ctx, variant, flavour):
     """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
@@ -433,7 +433,7 @@ def test_default_layout_follows_launch_size(ctx):
     ctx.resize(W, H)
     try:
         frames = []
-        for fl in (0, 6, 7, 8, 10, 11, 12, 13):
+        for fl in (0, 6, 7, 8, 10, 11, 12, 13, 15):
             ctx.set_kernel_flavour(fl)
             frag, _, n = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
             frames.append((vt.bits(frag), n))
@@ -672,7 +672,7 @@ def test_fused_every_variant_every_loop_form(fused, variant):
     W, H = 70, 45
     vols, tfs = vt.scene(variant, n=24)
     step, count = hr.stepping_params(24, 24, 24)
-    for fl in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
+    for fl in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
         fused.set_kernel_flavour(fl)
         for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
                    dict(distance=0.7, yaw=1.0)):
@@ -692,7 +692,7 @@ def test_fused_empty_space_skipping_is_exact(fused, variant, zeros):
     for cam in (dict(yaw=0.9, pitch=-0.3), dict(yaw=-2.1, pitch=0.6, distance=0.85)):
         u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam)
         outs = []
-        for fl in (0, 1, 5, 11, 12, 13):
+        for fl in (0, 1, 5, 11, 12, 13, 15):
             fused.set_kernel_flavour(fl)
             frag, n_s = check(fused, variant, u, vols, tfs, W, H)
             outs.append((vt.bits(frag), n_s))
@@ -1065,3 +1065,44 @@ def test_mixed_lanes_per_ray_at_1080p_and_every_threshold(ctx, monkeypatch):
                 c2.render_tiles(capi.LIGHT, 1, 2)
                 t, nt = c2.download_tiles(c2.tile_count(1, 2))
                 assert nt == nt_ref and np.array_equal(vt.bits(t), vt.bits(tiles_ref)), (pct, k)
+
+
+# ---- LDS tiles filled by LDS-DMA (flavour 15, csrc/vr_lt.h) ------------------------------------------------------------------
+def test_lds_tiles_by_lds_dma(ctx):
+    """Flavour 15: the voxels of the next four steps of a packet are fetched once into the wavefront's LDS tile by
+    global_load_lds_dwordx4 and the corner gathers read LDS.  Volumes whose boxes fit and volumes whose boxes do not (a 200^3
+    volume seen from 0.6: the rays of a packet fan out over more than a tile), every storage layout, clips, variable step,
+    jitter, hostile table positions, a ragged viewport and a 1080p frame: bit-equal to the oracle, counts included."""
+    try:
+        ctx.set_kernel_flavour(15)
+        for n, W, H in ((24, 70, 45), (64, 96, 80), (17, 33, 29)):
+            vols, tfs = vt.scene(capi.LIGHT, n=n)
+            step, count = hr.stepping_params(n, n, n)
+            for layout in (0, 3, 1):
+                ctx.set_volume_layout(layout)
+                for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
+                           dict(distance=0.62, yaw=1.0), dict(yaw=1.5707, pitch=0.0, distance=0.8), dict(steps_count=7)):
+                    args = dict(steps_count=count, step_size=step)
+                    args.update(kw)
+                    check(ctx, capi.LIGHT, hr.make_uniforms(W, H, **args), vols, tfs, W, H)
+                    assert ctx.last_kernel_flavour() == 15
+            ctx.set_volume_layout(0)
+            tfz = [zero_prefix_tf(64, 9)]
+            check(ctx, capi.LIGHT, hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=0.3), vols, tfz, W, H)
+        # 1080p, few voxels per pixel (boxes of a handful of voxels) and many (boxes that do not fit)
+        W, H = 1920, 1080
+        ctx.resize(W, H)
+        for n, dist in ((24, 0.9), (96, 0.7)):
+            vols, tfs = vt.scene(capi.LIGHT, n=n)
+            step, count = hr.stepping_params(n, n, n)
+            u = hr.make_uniforms(W, H, steps_count=count, step_size=step, distance=dist)
+            ctx.set_kernel_flavour(6)
+            ref, _, n_ref = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+            ctx.set_kernel_flavour(15)
+            for k in range(5):
+                frag, _, ns = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+                assert ns == n_ref and np.array_equal(vt.bits(frag), vt.bits(ref)), (n, k)
+    finally:
+        ctx.set_kernel_flavour(0)
+        ctx.set_volume_layout(0)
+        ctx.resize(96, 80)

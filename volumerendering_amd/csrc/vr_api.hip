@@ -358,15 +358,15 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     auto use_bricked = [&]() {
         for (int i = 0; i < VR_MAX_VOLUMES; ++i) {
             if (!c->vol[i].data || !c->vol_bricked[i] || !c->vol_bdens[i]) continue;
-            const unsigned nbx = ((unsigned)c->vol[i].nx + 3u) >> 2, nby = ((unsigned)c->vol[i].ny + 3u) >> 2, nbz = ((unsigned)c->vol[i].nz + 3u) >> 2;
-            const size_t slots = (size_t)nbx * nby * nbz * 64;
+            const unsigned nbx = ((unsigned)c->vol[i].nx + kVbM) >> kVbS, nby = ((unsigned)c->vol[i].ny + kVbM) >> kVbS, nbz = ((unsigned)c->vol[i].nz + kVbM) >> kVbS;
+            const size_t slots = (size_t)nbx * nby * nbz * kVbN;
             if (slots > 0xFFFFFFFFull) continue;  // (indices are 32 bits)
             P.vol[i].data = c->vol_bricked[i];
             P.vol[i].a_base = reinterpret_cast<const char*>(c->vol_bdens[i]);
             P.vol[i].a_shift = 2;
             P.vol[i].bricked = 1;
-            P.vol[i].brick_row = nbx * 64u;
-            P.vol[i].brick_slab = nbx * nby * 64u;
+            P.vol[i].brick_row = nbx * kVbN;
+            P.vol[i].brick_slab = nbx * nby * kVbN;
             P.vol[i].data_bytes = slots * 16 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)(slots * 16);
         }
     };
@@ -389,6 +389,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                               variant == VR_VARIANT_LIGHT_INSHADER;
     const int sv = (variant == VR_VARIANT_VOLUME_MASK) ? 2 : 0;  // the volume whose density drives tf[0]'s opacity
     int fl = c->flavour == 0 ? c->default_flavour : c->flavour;
+    unsigned chain_known = 0;  // longest ray chain + 1 of the most recent launch of this scene shape whose sort has reported (0: none)
     if (fl == 0) {
         // Default: pick the lanes per ray from what will be on the machine.  With many rays per hardware lane the machine is
         // throughput-bound and one lane per ray does the least work; with few (a small frame, or one GPU's share of the
@@ -418,11 +419,14 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 }
             }
         }
+        chain_known = chain;
         const bool short_chains = chain != 0 && chain - 1 < 128;
         fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
     }
     // persistent wavefronts (12; vr_pw.h) exist for launches of one frame
     if ((fl == 12 || fl == 13) && n_frames != 1) fl = 6;
+    // LDS tiles (15; vr_lt.h): the lit shader, launches of one frame
+    if (fl == 15 && (n_frames != 1 || variant != VR_VARIANT_LIGHT)) fl = 6;
     // mixed lanes per ray (14; vr_mixed.h): launches of one frame, shaders that have a depth-parallel form
     if (fl == 14 && (n_frames != 1 || variant == VR_VARIANT_ILLUSTRATIVE || variant == VR_VARIANT_LIGHT_INSHADER)) fl = 6;
     // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
@@ -508,22 +512,25 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     }
 
     // Default choice, second part: the persistent kernel (vr_pw.h: TF slot 0 in LDS, 4 wavefronts per SIMD, one launch at a time on
-    // the machine) where it measured faster than the one-lane kernel on whole frames -- volumes in which next to nothing can be
-    // skipped (noisy air under the default ramp: 3.62 -> 2.90 ms, the texture addressers lose the table texels) and the
-    // three-volume composite (C4: 0.68 -> 0.57 ms); it loses where most of the frame is skipped or thin (C2 0.10 -> 0.14, C5
-    // 3.35 -> 3.65, thin table 0.78 -> 0.85) and draws level on C3 (gpurun_out/r3b, r3d).
-    if (c->flavour == 0 && c->default_flavour == 0 && c->pw_policy && fl == 6 && n_frames == 1 && off32) {
+    // the machine) where it measured faster than the one-lane kernel on whole frames of the bricked layout, one frame at a
+    // time (turntable, ms per frame, gpurun_out/r3k): volumes in which next to nothing can be skipped (noisy air
+    // under the default ramp: 2.95 -> 2.61 with the corner loads pipelined) and rays that hardly terminate (the longest chain
+    // of an earlier launch >= 400 samples -- the thin table: 0.80 -> 0.73).  It loses where most of the frame is skipped (C2
+    // 0.13 -> 0.17, C5 3.33 -> 3.84), on the three-volume composite (0.74 -> 0.78) and with other launches in flight (its
+    // workgroups fill the machine: a second launch waits), and is level within the spread between boxes on C3's default table.
+    if (c->flavour == 0 && c->default_flavour == 0 && c->pw_policy && fl == 6 && n_frames == 1 && off32 && c->frames_in_flight == 1 &&
+        (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC)) {
         const long long px_all = (long long)tile_count(c, rank, world) * kTile * kTile;
         const bool whole_frame = (double)px_all / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 4.5;
         const bool nothing_to_skip = !can_skip || c->active_fraction >= 0.9;
-        if (whole_frame && variant == VR_VARIANT_VOLUME_MASK) fl = 12;
-        else if (whole_frame && (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC) && nothing_to_skip) fl = 13;
+        if (whole_frame && nothing_to_skip) fl = 13;
+        else if (whole_frame && chain_known >= 400u + 1u) fl = 12;
         c->last_flavour = fl;
     }
 
     if (c->layout_mode == 0 && fl != 2 && fl != 3) use_bricked();
     for (int i = 0; i < nvol; ++i)  // (a bricked copy is padded to whole bricks: a volume just below 4 GiB may cross the line)
-        if (P.vol[i].bricked && (size_t)P.vol[i].brick_slab * (((unsigned)P.vol[i].nz + 3u) >> 2) * 16 > 0xFFFFFFFFull) off32 = false;
+        if (P.vol[i].bricked && (size_t)P.vol[i].brick_slab * (((unsigned)P.vol[i].nz + kVbM) >> kVbS) * 16 > 0xFFFFFFFFull) off32 = false;
 
     if (packed && !out) {
         size_t need = (size_t)P.n_tiles * kTile * kTile;
@@ -560,7 +567,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // a 0.12 ms frame)
         const bool pw = fl == 12 || fl == 13;
         if (pw && c->pw_xcd_mode >= 0) P.xcd_mode = c->pw_xcd_mode;
-        int wpb = wtb ? 4 : (pw ? 1 : c->waves_per_block);
+        int wpb = wtb ? 4 : ((pw || fl == 15) ? 1 : c->waves_per_block);
         if (dp && P.n_tiles * (dp == 4 ? 256 : 128) > 16384) wpb = 4;
         dim3 block((unsigned)(64 * wpb));
         dim3 grid((unsigned)(dp ? P.n_tiles * (dp == 4 ? 256 : 128) / wpb : (P.n_tiles + 7) / 8 * 8 * (64 / wpb)));  // see map_pixel / map_pixel_dp
@@ -638,6 +645,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.dp_pipe = dp_pipe;
             L.wtb = wtb;
             L.otf = otf;
+            L.lt = fl == 15;
             L.pw = false;
             L.pw_ltf = false;
             L.pw_pipe = false;
@@ -820,8 +828,8 @@ int refresh_bricks(vr_ctx* c, int slot)
     c->vol_grad_derived[slot] = flag == 0;
     c->vol[slot].dens = c->vol_dens[slot];
     {   // the bricked copy the march kernels gather from (DevVolume::bricked)
-        const unsigned nbx = ((unsigned)v.nx + 3u) >> 2, nby = ((unsigned)v.ny + 3u) >> 2, nbz = ((unsigned)v.nz + 3u) >> 2;
-        const size_t slots = (size_t)nbx * nby * nbz * 64;
+        const unsigned nbx = ((unsigned)v.nx + kVbM) >> kVbS, nby = ((unsigned)v.ny + kVbM) >> kVbS, nbz = ((unsigned)v.nz + kVbM) >> kVbS;
+        const size_t slots = (size_t)nbx * nby * nbz * kVbN;
         if (slots > c->vol_bricked_cap[slot]) {
             if (c->vol_bricked[slot]) (void)hipFree(c->vol_bricked[slot]);
             if (c->vol_bdens[slot]) (void)hipFree(c->vol_bdens[slot]);
@@ -1627,7 +1635,7 @@ int vr_volume_layout(vr_ctx* c, int slot, int* flags)
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 14) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 15) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     c->flavour = flavour;
     return VR_OK;
 }

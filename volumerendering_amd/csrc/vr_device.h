@@ -24,6 +24,14 @@ constexpr int kBrickCells = 1 << kBrickShift;
 constexpr float kBrickInv = 1.0f / (float)kBrickCells;    // exact
 constexpr float kBrickHalf = 0.5f / (float)kBrickCells;   // half a cell in brick units (the -0.5 of the cell coordinate)
 constexpr int kDistMax = 16;      // cap of the brick distance field (leaps of up to 15 bricks)
+// Storage bricks of the bricked volume copy (DevVolume::bricked): 2^S voxels per axis, S = 2 (4 x 4 x 4 = 1 KiB of vec4 voxels)
+// by default; -DVR_VOX_BRICK_SHIFT=1 / 3 rebuilds with 2^3- / 8^3-voxel bricks for A/B (tools/run_r3l.sh).
+#ifndef VR_VOX_BRICK_SHIFT
+#define VR_VOX_BRICK_SHIFT 2
+#endif
+constexpr unsigned kVbS = VR_VOX_BRICK_SHIFT;          // log2 of the brick edge
+constexpr unsigned kVbM = (1u << kVbS) - 1u;           // mask of the in-brick coordinate
+constexpr unsigned kVbN = 1u << (3u * kVbS);           // voxels per brick
 
 struct DevVolume {
     const float4* data;  // reference layout: x fastest, (k*ny + j)*nx + i   (VolumeFile.cpp:306)
@@ -39,6 +47,7 @@ struct DevVolume {
     // Bricked layout (default, vr_set_volume_layout(0)): `data` and the density plane behind `a_base` hold the voxels
     // in bricks of 4 x 4 x 4, brick after brick (x fastest), the 64 voxels of a brick in x-fastest order: voxel (x, y, z) lives at
     //     (x >> 2) * 64 + (x & 3)  +  (y >> 2) * brick_row + (y & 3) * 4  +  (z >> 2) * brick_slab + (z & 3) * 16
+    // (written with kVbS / kVbM / kVbN in the code: the brick edge is a build-time constant)
     // -- a sum of one term per axis, so the eight corners of a cell are sums of two terms per axis.  A 1 KiB brick is eight
     // 128-byte lines of 4 x 2 x 1 voxels: the 7 x 7 x 2 voxel patch a packet's corner load touches spans ~20 lines instead of
     // the ~30 of the reference's x-fastest rows, and the lines a ray needs next lie in the same or the neighbouring brick
@@ -133,6 +142,7 @@ struct LaunchDesc {
     bool dp_pipe;     // ... with the next round's corner loads software-pipelined
     bool wtb;         // LDS wave-tile kernel (lit shader, separate arithmetic only)
     bool otf;         // lit shader: corner gradients derived from the density plane
+    bool lt;          // LDS tiles filled by LDS-DMA (vr_lt.h; lit shader)
     bool pw;          // persistent wavefronts (vr_pw.h): grid = workgroups of 1024 threads, the packets come from `queue`
     bool pw_ltf;      // ... with TF slot 0 in LDS (lds_bytes of dynamic LDS)
     bool pw_pipe;     // ... with the next step's corner loads software-pipelined (lit / unlit shader)

@@ -256,11 +256,11 @@ __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
             texel_pair(y0, v.ny, j0, j1);
             texel_pair(z0, v.nz, k0, k1);
         }
-        const unsigned ax0 = ((unsigned)i0 >> 2) * 64u + ((unsigned)i0 & 3u), ax1 = ((unsigned)i1 >> 2) * 64u + ((unsigned)i1 & 3u);
-        const unsigned ay0 = ((unsigned)j0 >> 2) * v.brick_row + (((unsigned)j0 & 3u) << 2);
-        const unsigned ay1 = ((unsigned)j1 >> 2) * v.brick_row + (((unsigned)j1 & 3u) << 2);
-        const unsigned az0 = ((unsigned)k0 >> 2) * v.brick_slab + (((unsigned)k0 & 3u) << 4);
-        const unsigned az1 = ((unsigned)k1 >> 2) * v.brick_slab + (((unsigned)k1 & 3u) << 4);
+        const unsigned ax0 = ((unsigned)i0 >> kVbS) * kVbN + ((unsigned)i0 & kVbM), ax1 = ((unsigned)i1 >> kVbS) * kVbN + ((unsigned)i1 & kVbM);
+        const unsigned ay0 = ((unsigned)j0 >> kVbS) * v.brick_row + (((unsigned)j0 & kVbM) << kVbS);
+        const unsigned ay1 = ((unsigned)j1 >> kVbS) * v.brick_row + (((unsigned)j1 & kVbM) << kVbS);
+        const unsigned az0 = ((unsigned)k0 >> kVbS) * v.brick_slab + (((unsigned)k0 & kVbM) << (2u * kVbS));
+        const unsigned az1 = ((unsigned)k1 >> kVbS) * v.brick_slab + (((unsigned)k1 & kVbM) << (2u * kVbS));
         const unsigned r00 = ay0 + az0, r10 = ay1 + az0, r01 = ay0 + az1, r11 = ay1 + az1;
         c.o000 = r00 + ax0; c.o100 = r00 + ax1;
         c.o010 = r10 + ax0; c.o110 = r10 + ax1;
@@ -566,8 +566,8 @@ __device__ __forceinline__ float4 tex3_nearest(const DevVolume& v, f3 p)
     int k = clampi((int)floorf(p.z * (float)v.nz), 0, v.nz - 1);
     unsigned idx = ((unsigned)k * (unsigned)v.ny + (unsigned)j) * (unsigned)v.nx + (unsigned)i;
     if (v.bricked)
-        idx = ((unsigned)i >> 2) * 64u + ((unsigned)i & 3u) + ((unsigned)j >> 2) * v.brick_row + (((unsigned)j & 3u) << 2) +
-              ((unsigned)k >> 2) * v.brick_slab + (((unsigned)k & 3u) << 4);
+        idx = ((unsigned)i >> kVbS) * kVbN + ((unsigned)i & kVbM) + ((unsigned)j >> kVbS) * v.brick_row + (((unsigned)j & kVbM) << kVbS) +
+              ((unsigned)k >> kVbS) * v.brick_slab + (((unsigned)k & kVbM) << (2u * kVbS));
     return load_vec4<OFF32>(v.data, idx);
 }
 
@@ -1880,18 +1880,19 @@ __global__ void merge_bricks_kernel(const float2* __restrict__ density_vol, cons
 }
 
 // ---- bricked copy of a volume (DevVolume::bricked; rebuilt with the brick records after every upload or in-place change) -----
-// One thread per slot of the bricked arrays: slot s = brick * 64 + (lz * 16 + ly * 4 + lx); voxels beyond the volume's faces
-// (the last brick of an axis whose size is not a multiple of 4) are zero and never addressed.
+// One thread per slot of the bricked arrays: slot s = brick * 64 + (lz * 16 + ly * 4 + lx) for the default 4 x 4 x 4 bricks;
+// voxels beyond the volume's faces (the last brick of an axis whose size is not a multiple of the brick edge) are zero and
+// never addressed.
 __global__ void rebrick_kernel(const float4* __restrict__ lin, float4* __restrict__ bvol, float* __restrict__ bdens, int nx, int ny,
                                int nz, unsigned nbx, unsigned nby, size_t n_slots)
 {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; s < n_slots; s += stride) {
-        const unsigned l = (unsigned)(s & 63u);
-        const size_t b = s >> 6;
+        const unsigned l = (unsigned)(s & (kVbN - 1u));
+        const size_t b = s >> (3u * kVbS);
         const unsigned bx = (unsigned)(b % nbx), by = (unsigned)((b / nbx) % nby), bz = (unsigned)(b / ((size_t)nbx * nby));
-        const int x = (int)(bx * 4u + (l & 3u)), y = (int)(by * 4u + ((l >> 2) & 3u)), z = (int)(bz * 4u + (l >> 4));
+        const int x = (int)((bx << kVbS) + (l & kVbM)), y = (int)((by << kVbS) + ((l >> kVbS) & kVbM)), z = (int)((bz << kVbS) + (l >> (2u * kVbS)));
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (x < nx && y < ny && z < nz) v = lin[((size_t)z * ny + y) * nx + x];
         bvol[s] = v;

@@ -8,6 +8,7 @@
 #include "vr_dp.h"
 #include "vr_pw.h"
 #include "vr_mixed.h"
+#include "vr_lt.h"
 #if !VR_FUSED
 #include "vr_wtb.h"
 #endif
@@ -136,6 +137,17 @@ void launch_mixed(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 {
     const int variant = L.variant;
+    if (L.lt) {  // LDS tiles (vr_lt.h): lit shader
+        const bool skip = B.frame[0].brick_dist != nullptr;
+        if (L.off32) {
+            if (skip) hipLaunchKernelGGL((march_lt_kernel<true, true>), L.grid, L.block, 0, s, B);
+            else hipLaunchKernelGGL((march_lt_kernel<true, false>), L.grid, L.block, 0, s, B);
+        } else {
+            if (skip) hipLaunchKernelGGL((march_lt_kernel<false, true>), L.grid, L.block, 0, s, B);
+            else hipLaunchKernelGGL((march_lt_kernel<false, false>), L.grid, L.block, 0, s, B);
+        }
+        return;
+    }
     if (L.mixed_items) {
         switch (variant) {
         case VR_VARIANT_BASIC: launch_mixed<V_BASIC>(L, s, B); break;
