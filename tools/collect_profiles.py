@@ -48,7 +48,7 @@ def main():
     if RND == "02":
         pairs = (("trace", "r02_c3_overlapped_kernel_stats.csv"), ("trace_serial", "r02_c3_serial_kernel_stats.csv"))
     else:
-        pairs = (("trace", f"r{RND}_c3_bench_kernel_stats.csv"),)
+        pairs = (("trace", f"r{RND}_c3_bench_kernel_stats.csv"), ("trace_serial", f"r{RND}_c3_serial_kernel_stats.csv"))
     for t, dst in pairs:
         f = newest(os.path.join(SRC, t, "*", "*kernel_stats.csv"))
         if f:
