@@ -300,6 +300,7 @@ int vr_last_counters(vr_ctx* ctx, uint64_t out[3]);
 int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
 
 /* Kernel flavour for A/B measurements.  All flavours are bit-identical in output and in the sample counts.
+ * (2, 3, 4, 5 and 9 exist only in builds with -DVR_EXPERIMENTAL_FLAVOURS=1: vr_experimental_flavours below.)
  *   0  default: exact empty-space skipping + wave-uniform runs through inert bricks; lanes per ray chosen from
  *      what will be on the machine -- the size of the launch (frames per launch included) times the launches the
  *      caller keeps in flight (vr_hint_frames_in_flight) -- and from the longest ray chain of an earlier launch of the same scene: one lane
@@ -321,6 +322,11 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *      shape reached 75 % of that launch's longest are marched as two half packets with two lanes per ray, the rest with
  *      one; one-frame launches of the shaders that have a depth-parallel form                                  */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
+
+/* 1 if the library was built with -DVR_EXPERIMENTAL_FLAVOURS=1: the kernel forms that lost every A/B -- flavours 2, 3, 4, 5, 9
+ * and volume layout 2 -- are then compiled in; 0 (the shipped build): vr_set_kernel_flavour / vr_set_volume_layout return
+ * VR_ERR_UNSUPPORTED for them.                                                                                           */
+int vr_experimental_flavours(void);
 
 /* Arithmetic mode.  WGSL leaves it to the implementation whether `a * b + c` is evaluated with one rounding or two
  * (the reference's Tint -> HLSL -> D3D12 back end emits `mad`).

@@ -233,7 +233,7 @@ def test_skipping_with_hostile_values(ctx):
     tf = zero_prefix_tf(32, 3)
     for variant in (capi.BASIC, capi.LIGHT, capi.LIGHT_INSHADER):
         ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
-        for flavour in (0, 1, 5, 6, 8, 9, 11, 12, 13, 14, 15):  # every loop form and lanes-per-ray layout
+        for flavour in vt.flavours(0, 1, 5, 6, 8, 9, 11, 12, 13, 14, 15):  # every loop form and lanes-per-ray layout
             ctx.set_kernel_flavour(flavour)
             frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
             assert same(frag, ref) and ns == n_ref, (variant, flavour)
@@ -315,6 +315,7 @@ def test_volume_mask_skipping_respects_the_mask(ctx):
     assert ctx.counters()[2] == ns
 
 
+@pytest.mark.skipif(not vt.experimental(), reason="flavours 2 / 3 need VR_EXPERIMENTAL_FLAVOURS=1")
 @pytest.mark.parametrize("flavour", [2, 3])
 def test_lds_wave_tile_flavours_are_exact(ctx, flavour):
     """Flavours 2 / 3 stage the voxels of the lit shader through LDS wave tiles: same frame, same counts."""
@@ -367,7 +368,7 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
                 assert ctx.counters()[2] < 0.5 * ns
 
 
-@pytest.mark.parametrize("flavour", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15])
+@pytest.mark.parametrize("flavour", vt.flavours(4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15))
 def test_exact_leaping_flavour(ctx, flavour):
     """Every way of getting through empty space and every lanes-per-ray layout must reproduce the step-by-step
     accumulation bit for bit (frames AND sample counts): 5 single steps, 6 wave-uniform runs of plain additions,
@@ -405,7 +406,7 @@ def test_exact_leaping_flavour(ctx, flavour):
         ctx.set_kernel_flavour(0)
 
 
-@pytest.mark.parametrize("flavour", [6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("flavour", vt.flavours(6, 7, 8, 9, 10, 11, 12, 13, 14, 15))
 @pytest.mark.parametrize("variant", range(8))
 def test_every_variant_every_layout(ctx, variant, flavour):
     """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
@@ -545,7 +546,7 @@ def test_density_plane_and_on_the_fly_gradients_are_exact(ctx):
                 args = dict(steps_count=count, step_size=step)
                 args.update(kw)
                 u = hr.make_uniforms(W, H, **args)
-                for mode in (0, 1, 2):
+                for mode in vt.layouts(0, 1, 2, 3):
                     ctx.set_volume_layout(mode)
                     for fl in (0, 6, 1):
                         ctx.set_kernel_flavour(fl)
@@ -559,6 +560,7 @@ def test_density_plane_and_on_the_fly_gradients_are_exact(ctx):
         ctx.set_kernel_flavour(0)
 
 
+@pytest.mark.skipif(not vt.experimental(), reason="volume layout 2 needs VR_EXPERIMENTAL_FLAVOURS=1")
 def test_gradient_verification_and_boundary_cells(ctx):
     W, H = 72, 56
     ctx.set_kernel_flavour(6)
@@ -672,7 +674,7 @@ def test_fused_every_variant_every_loop_form(fused, variant):
     W, H = 70, 45
     vols, tfs = vt.scene(variant, n=24)
     step, count = hr.stepping_params(24, 24, 24)
-    for fl in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
+    for fl in vt.flavours(0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
         fused.set_kernel_flavour(fl)
         for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
                    dict(distance=0.7, yaw=1.0)):
@@ -692,7 +694,7 @@ def test_fused_empty_space_skipping_is_exact(fused, variant, zeros):
     for cam in (dict(yaw=0.9, pitch=-0.3), dict(yaw=-2.1, pitch=0.6, distance=0.85)):
         u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam)
         outs = []
-        for fl in (0, 1, 5, 11, 12, 13, 15):
+        for fl in vt.flavours(0, 1, 5, 11, 12, 13, 15):
             fused.set_kernel_flavour(fl)
             frag, n_s = check(fused, variant, u, vols, tfs, W, H)
             outs.append((vt.bits(frag), n_s))
@@ -705,7 +707,7 @@ def test_fused_layouts_hostile_values_and_mode_switching(fused):
     vols, tfs = vt.scene(capi.LIGHT, n=24)
     step, count = hr.stepping_params(24, 24, 24)
     u = hr.make_uniforms(W, H, steps_count=count, step_size=step)
-    for mode in (0, 1, 2):
+    for mode in vt.layouts(0, 1, 2, 3):
         fused.set_volume_layout(mode)
         for fl in (6, 1):
             fused.set_kernel_flavour(fl)
@@ -907,7 +909,7 @@ def test_kernel_times_from_the_launch_records_agree_with_events(ctx):
         warnings.warn(f"HIP events read {excess * 1e3:.0f} us more than the launch records (busy box?): {list(kt)} vs {ev}")
 
 
-@pytest.mark.parametrize("mode", ["fused", "otf"])
+@pytest.mark.parametrize("mode", ["fused"] + (["otf"] if vt.experimental() else []))
 def test_batched_launches_in_the_other_kernel_families(ctx, mode):
     """The batch instantiations of the fused-arithmetic kernels (namespace vrf) and of the gradients-on-the-fly kernel are
     separate code: each frame of a four-frame launch equals the single-frame render of the same mode bit for bit."""

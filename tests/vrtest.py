@@ -70,3 +70,24 @@ def gpu_render(ctx, variant, u, volumes, tfs, present=False):
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ---- kernel forms of the build under test -----------------------------------------------------------------------------------
+# Flavours 2, 3, 4, 5, 9 and volume layout 2 lost every A/B and are compiled only with VR_EXPERIMENTAL_FLAVOURS=1
+# (csrc/vr_launch.h); the shipped library rejects them.  Tests take their flavour / layout lists through these filters, so the
+# same suite covers both builds.
+def experimental() -> bool:
+    try:
+        return capi.experimental_flavours()
+    except Exception:  # noqa: BLE001  (library not built: the GPU tests that would use the list cannot run anyway)
+        return False
+
+
+def flavours(*fl):
+    ex = experimental()
+    return [f for f in fl if ex or f not in (2, 3, 4, 5, 9)]
+
+
+def layouts(*modes):
+    ex = experimental()
+    return [m for m in modes if ex or m != 2]

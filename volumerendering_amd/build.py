@@ -36,6 +36,13 @@ def build_hip(force: bool = False) -> str:
     hdrs = [os.path.join(CSRC, f) for f in ("vr_kernels.h", "vr_wtb.h", "vr_dp.h", "vr_pw.h", "vr_mixed.h", "vr_lt.h", "vr_device.h", "vr_launch.h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "vr.h"))
     flags = [f for f in HIP_FLAGS if f != "-shared"] + os.environ.get("VR_EXTRA_HIPCC_FLAGS", "").split()
+    if os.environ.get("VR_EXPERIMENTAL_FLAVOURS", "0") not in ("", "0"):
+        flags.append("-DVR_EXPERIMENTAL_FLAVOURS=1")  # the kernel forms that lost every A/B (vr_launch.h)
+    # the flags the objects were compiled with: a change (VR_EXTRA_HIPCC_FLAGS, VR_EXPERIMENTAL_FLAVOURS) rebuilds them
+    stamp = os.path.join(CSRC, ".build_flags")
+    want = " ".join(flags)
+    if not os.path.exists(stamp) or open(stamp).read() != want:
+        force = True
     objs, procs = [], []
     for name in ("vr_api", "vr_fused"):
         src, obj = os.path.join(CSRC, name + ".hip"), os.path.join(CSRC, name + ".o")
@@ -47,6 +54,8 @@ def build_hip(force: bool = False) -> str:
             raise subprocess.CalledProcessError(pr.returncode, f"hipcc {name}.hip")
     if procs or force or _newer(target, objs):
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, *objs], check=True)
+    with open(stamp, "w") as fh:
+        fh.write(want)
     return target
 
 

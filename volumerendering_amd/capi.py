@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "vr_render_batch_async", "vr_render_tiles_batch_async", "vr_unpack_tiles_strided_async",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
     "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream", "vr_hint_frames_in_flight",
-    "vr_set_kernel_timing", "vr_present_tiles_async", "vr_last_split_packets",
+    "vr_set_kernel_timing", "vr_present_tiles_async", "vr_last_split_packets", "vr_experimental_flavours",
 ]
 
 
@@ -49,6 +49,11 @@ class Uniforms(C.Structure):
         ("toggles", C.c_int32 * 4),
         ("light_pos", C.c_float * 4), ("light_ambient", C.c_float * 4), ("light_diffuse", C.c_float * 4),
     ]
+
+
+def experimental_flavours() -> bool:
+    """True if libvr_hip.so was built with -DVR_EXPERIMENTAL_FLAVOURS=1 (flavours 2, 3, 4, 5, 9 and layout 2 compiled in)."""
+    return bool(load().vr_experimental_flavours())
 
 
 class VrError(RuntimeError):
@@ -113,6 +118,7 @@ def load() -> C.CDLL:
     lib.vr_set_kernel_flavour.argtypes = [vp, i32]
     lib.vr_last_kernel_flavour.argtypes = [vp]
     lib.vr_last_split_packets.argtypes = [vp]
+    lib.vr_experimental_flavours.argtypes = []
     lib.vr_set_volume_layout.argtypes = [vp, i32]
     lib.vr_set_arithmetic.argtypes = [vp, i32]
     lib.vr_present_async.argtypes = [vp, vp, vp, vp]

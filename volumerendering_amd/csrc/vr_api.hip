@@ -1009,7 +1009,10 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_WAVES_PER_BLOCK")) c->waves_per_block = (atoi(e) == 4) ? 4 : 1;
     if (const char* e = getenv("VR_EXP_ONLY_TILE")) c->only_tile = atoi(e);
     if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
-    if (const char* e = getenv("VR_EXP_FLAVOUR")) c->default_flavour = atoi(e);
+    if (const char* e = getenv("VR_EXP_FLAVOUR")) {
+        const int f = atoi(e);
+        if (f >= 0 && f <= 15 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9))) c->default_flavour = f;
+    }
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
     if (const char* e = getenv("VR_EXP_PW_STEAL")) c->pw_steal = atoi(e) != 0;
@@ -1524,6 +1527,8 @@ int vr_last_kernel_flavour(vr_ctx* c)
     return c->last_flavour;
 }
 
+int vr_experimental_flavours(void) { return VR_EXPERIMENTAL_FLAVOURS ? 1 : 0; }
+
 int vr_last_split_packets(vr_ctx* c)
 {
     if (!c) return VR_ERR_INVALID_ARG;
@@ -1618,6 +1623,8 @@ int vr_set_volume_layout(vr_ctx* c, int mode)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     if (mode < 0 || mode > 3) return fail(c, VR_ERR_INVALID_ARG, "vr_set_volume_layout: unknown mode");
+    if (!VR_EXPERIMENTAL_FLAVOURS && mode == 2)
+        return fail(c, VR_ERR_UNSUPPORTED, "vr_set_volume_layout: layout 2 is compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
     c->layout_mode = mode;
     return VR_OK;
 }
@@ -1636,6 +1643,8 @@ int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     if (flavour < 0 || flavour > 15) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (!VR_EXPERIMENTAL_FLAVOURS && (flavour == 2 || flavour == 3 || flavour == 4 || flavour == 5 || flavour == 9))
+        return fail(c, VR_ERR_UNSUPPORTED, "vr_set_kernel_flavour: flavours 2, 3, 4, 5 and 9 are compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
     c->flavour = flavour;
     return VR_OK;
 }

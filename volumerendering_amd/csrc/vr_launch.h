@@ -9,7 +9,14 @@
 #include "vr_pw.h"
 #include "vr_mixed.h"
 #include "vr_lt.h"
-#if !VR_FUSED
+// Kernel forms that lost every A/B -- flavours 2 / 3 (register-staged LDS wave tiles), 4 (closed-form leaping),
+// 5 (skipping without runs), 9 (one lane per ray, pipelined corner loads) and layout 2 (gradients on the fly) -- are compiled
+// only with -DVR_EXPERIMENTAL_FLAVOURS=1 (VR_EXPERIMENTAL_FLAVOURS=1 in the environment of build.py): a third fewer march
+// kernel instantiations in the shipped library.  Without them vr_set_kernel_flavour / vr_set_volume_layout reject those values.
+#ifndef VR_EXPERIMENTAL_FLAVOURS
+#define VR_EXPERIMENTAL_FLAVOURS 0
+#endif
+#if !VR_FUSED && VR_EXPERIMENTAL_FLAVOURS
 #include "vr_wtb.h"
 #endif
 
@@ -33,6 +40,7 @@ void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, 
     } while (0)
     if constexpr (kCanSkip) {
         if (B.frame[0].brick_dist) {
+#if VR_EXPERIMENTAL_FLAVOURS
             if (off32) {
                 if (leap == 2) VR_LAUNCH(true, true, 2);
                 else if (leap == 3) VR_LAUNCH(true, true, 3);
@@ -44,6 +52,11 @@ void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, 
                 else if (leap == 1) VR_LAUNCH(false, true, 1);
                 else VR_LAUNCH(false, true, 0);
             }
+#else
+            (void)leap;  // (the loop form with runs is the only skipping form of the shipped library)
+            if (off32) VR_LAUNCH(true, true, 3);
+            else VR_LAUNCH(false, true, 3);
+#endif
             return;
         }
     }
@@ -174,9 +187,10 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         return;
     }
     const bool off32 = L.off32, dp_pipe = L.dp_pipe, otf = L.otf;
+    (void)otf;  // (used with VR_EXPERIMENTAL_FLAVOURS only)
     const int leap_mode = L.leap_mode, dp = L.dp;
     const dim3 grid = L.grid, block = L.block;
-#if !VR_FUSED
+#if !VR_FUSED && VR_EXPERIMENTAL_FLAVOURS
         if (L.wtb) {
             if (B.frame[0].brick_dist) {
                 if (off32) hipLaunchKernelGGL((march_wtb_light_kernel<true, true>), grid, dim3(256), 0, s, B);
@@ -217,8 +231,11 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         switch (variant) {
         case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, B); break;
         case VR_VARIANT_LIGHT:
+#if VR_EXPERIMENTAL_FLAVOURS
             if (otf) launch_variant<V_LIGHT, true>(off32, leap_mode, grid, block, s, B);
-            else launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, B);
+            else
+#endif
+                launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, B);
             break;
         case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, B); break;
         case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, B); break;
