@@ -424,7 +424,12 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
     }
     // persistent wavefronts (12; vr_pw.h) exist for launches of one frame
-    if ((fl == 12 || fl == 13) && n_frames != 1) fl = 6;
+    if ((fl == 12 || fl == 13 || fl == 16) && n_frames != 1) fl = 6;
+    // two steps ahead (16; march_p2_kernel): lit / unlit shader, TF slot 0 in LDS, the bricked copy below 4 GiB; else 13
+    if (fl == 16 && !((variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC) && c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c &&
+                      c->tf[0].res_o + 2 <= 8192 && c->layout_mode == 0 && c->vol_bricked[0] && c->vol_bdens[0] && off32 &&
+                      (size_t)c->vol_bricked_cap[0] * 16 <= 0xFFFFFFFFull))
+        fl = 13;
     // LDS tiles (15; vr_lt.h): the lit shader, launches of one frame
     if (fl == 15 && (n_frames != 1 || variant != VR_VARIANT_LIGHT)) fl = 6;
     // mixed lanes per ray (14; vr_mixed.h): launches of one frame, shaders that have a depth-parallel form
@@ -523,7 +528,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const long long px_all = (long long)tile_count(c, rank, world) * kTile * kTile;
         const bool whole_frame = (double)px_all / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 4.5;
         const bool nothing_to_skip = !can_skip || c->active_fraction >= 0.9;
-        if (whole_frame && nothing_to_skip) fl = 13;
+        // (16 = the no-skip kernel with the corner loads two steps ahead, when TF slot 0 fits LDS and the bricked copy is in
+        // use: noisy air 2.60 -> 2.16 ms; 13 otherwise)
+        if (whole_frame && nothing_to_skip)
+            fl = (c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c && c->tf[0].res_o + 2 <= 8192 && c->layout_mode == 0 && c->vol_bricked[0] &&
+                  c->vol_bdens[0] && (size_t)c->vol_bricked_cap[0] * 16 <= 0xFFFFFFFFull) ? 16 : 13;
         else if (whole_frame && chain_known >= 400u + 1u) fl = 12;
         c->last_flavour = fl;
     }
@@ -565,7 +574,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // one wavefront per workgroup (launch order at wavefront granularity) -- except for the depth-parallel kernels on
         // large launches, where 4x the workgroups cost more at dispatch than the finer order gains (C2: 32 768 workgroups of
         // a 0.12 ms frame)
-        const bool pw = fl == 12 || fl == 13;
+        const bool pw = fl == 12 || fl == 13 || fl == 16;
         if (pw && c->pw_xcd_mode >= 0) P.xcd_mode = c->pw_xcd_mode;
         int wpb = wtb ? 4 : ((pw || fl == 15) ? 1 : c->waves_per_block);
         if (dp && P.n_tiles * (dp == 4 ? 256 : 128) > 16384) wpb = 4;
@@ -649,6 +658,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.pw = false;
             L.pw_ltf = false;
             L.pw_pipe = false;
+            L.pw_p2 = false;
             L.lds_bytes = 0;
             L.queue = PwQueue{nullptr, 0u, 0u};
             L.mixed_items = nullptr;
@@ -673,17 +683,19 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 // persistent wavefronts: `grid` stays the number of LOGICAL blocks (records, launch order); the launch itself is one
                 // workgroup of 16 wavefronts per CU (fewer when there are fewer packets), TF slot 0 in LDS when its two tables
                 // have one resolution and fit beside nothing else (R <= 8190: 128 KiB)
-                const unsigned per_wg = 1024u / 64u;
+                const unsigned pw_threads = fl == 16 ? 768u : 1024u;  // (march_p2_kernel: two corner buffers, 3 wavefronts per SIMD)
+                const unsigned per_wg = pw_threads / 64u;
                 const unsigned wgs = (grid.x + per_wg - 1u) / per_wg;
                 L.pw = true;
                 L.pw_pipe = fl == 13;
+                L.pw_p2 = fl == 16;
                 L.pw_ltf = c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c && c->tf[0].res_o + 2 <= 8192;
                 L.lds_bytes = L.pw_ltf ? (unsigned)(c->tf[0].res_o + 2) * 16u : 0u;
                 L.queue.heads = c->d_pw_heads + (size_t)cb * 8 * 64;
                 L.queue.n_items = grid.x;
                 L.queue.steal = c->pw_steal ? 1u : 0u;
                 L.grid = dim3(wgs < (unsigned)c->n_cus ? wgs : (unsigned)c->n_cus);
-                L.block = dim3(1024);
+                L.block = dim3(pw_threads);
                 if (c->pw_heads_dirty[cb]) VR_HIP(c, hipMemsetAsync(L.queue.heads, 0, 8 * 64 * sizeof(unsigned), s));
                 c->pw_heads_dirty[cb] = !ordered;  // (an ordered launch's sort clears them behind it)
             }
@@ -1011,7 +1023,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_FLAVOUR")) {
         const int f = atoi(e);
-        if (f >= 0 && f <= 15 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9))) c->default_flavour = f;
+        if (f >= 0 && f <= 16 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9))) c->default_flavour = f;
     }
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
@@ -1642,7 +1654,7 @@ int vr_volume_layout(vr_ctx* c, int slot, int* flags)
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 15) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 16) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     if (!VR_EXPERIMENTAL_FLAVOURS && (flavour == 2 || flavour == 3 || flavour == 4 || flavour == 5 || flavour == 9))
         return fail(c, VR_ERR_UNSUPPORTED, "vr_set_kernel_flavour: flavours 2, 3, 4, 5 and 9 are compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
     c->flavour = flavour;

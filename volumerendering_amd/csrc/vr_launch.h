@@ -118,6 +118,20 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         else VR_LAUNCH_PW(O, S, false, false);                                                                         \
     } while (0)
     constexpr bool kCanPipe = (V == V_BASIC || V == V_LIGHT);
+    if constexpr (kCanPipe) {
+        if (L.pw_p2) {  // two steps ahead, no skipping (the host: TF slot 0 in LDS, bricked copy below 4 GiB)
+            auto k = march_p2_kernel<V>;
+            if (L.lds_bytes > 48u * 1024u) {
+                static unsigned raised = 0;
+                if (L.lds_bytes > raised) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
+                    raised = L.lds_bytes;
+                }
+            }
+            hipLaunchKernelGGL(k, L.grid, L.block, L.lds_bytes, s, B, L.queue);
+            return;
+        }
+    }
     if constexpr (kCanSkip) {
         if (skip) {
             if (L.off32) VR_LAUNCH_PW_T(true, true);

@@ -27,6 +27,7 @@
 // Arithmetic, positions, blend order and counts are march_packet's (vr_kernels.h): bit-identical frames and records.
 #pragma once
 #include "vr_kernels.h"
+#include <type_traits>
 
 namespace VR_KNS {
 using namespace vr;
@@ -87,6 +88,220 @@ __global__ __launch_bounds__(kPwThreads) void march_pw_kernel(const MarchBatch B
         if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
         const unsigned groups_cur = (gridDim.x - cur + 7u) >> 3;
         idx = groups_cur * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+    }
+}
+
+// ---- two steps ahead: the no-skip form (flavour 16) ---------------------------------------------------------------
+// Everything in a step but the blend is independent of the step before (positions are known in advance), so the remedy for a
+// frame made of latencies is a deeper software pipeline: two corner buffers (A = even steps, B = odd steps, the loop unrolled by
+// two so that which registers hold which step is static), the corners of step i + 2 requested as soon as step i's have been
+// interpolated, table texels from LDS.  Built for the regime that is nothing but sampling (no distance field, no runs, no vote:
+// the host picks it for volumes with nothing to skip): every ray samples from its entry into the box to its cut-off or exit.
+// Speculative loads of positions a ray never reaches read clamped, valid voxels and are dropped.  The loads are raw buffer
+// loads the compiler tracks (it places the s_waitcnt); kP2Threads keeps the register budget wide enough (256 VGPRs) that the
+// allocator has no reason to move a buffer while its loads are in flight.  Arithmetic per sample: light_shade_blend / blend.
+constexpr int kP2Threads = 768;  // 12 wavefronts per CU, 3 per SIMD (165 VGPRs: two corner buffers are 64 of them)
+
+// Branch-free cell of a BRICKED volume: clamp-to-edge texel pairs on every axis, separable index (make_cell's arithmetic
+// without its wave-uniform fast paths: a branch between address arithmetic and loads defeats the wait-count pass).
+__device__ __forceinline__ Cell make_cell_bricked(const DevVolume& v, f3 p)
+{
+    const float x = mad(p.x, (float)v.nx, -0.5f), y = mad(p.y, (float)v.ny, -0.5f), z = mad(p.z, (float)v.nz, -0.5f);
+    const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+    Cell c;
+    c.fx = x - x0;
+    c.fy = y - y0;
+    c.fz = z - z0;
+    int i0, i1, j0, j1, k0, k1;
+    texel_pair(x0, v.nx, i0, i1);
+    texel_pair(y0, v.ny, j0, j1);
+    texel_pair(z0, v.nz, k0, k1);
+    const unsigned ax0 = ((unsigned)i0 >> kVbS) * kVbN + ((unsigned)i0 & kVbM), ax1 = ((unsigned)i1 >> kVbS) * kVbN + ((unsigned)i1 & kVbM);
+    const unsigned ay0 = ((unsigned)j0 >> kVbS) * v.brick_row + (((unsigned)j0 & kVbM) << kVbS);
+    const unsigned ay1 = ((unsigned)j1 >> kVbS) * v.brick_row + (((unsigned)j1 & kVbM) << kVbS);
+    const unsigned az0 = ((unsigned)k0 >> kVbS) * v.brick_slab + (((unsigned)k0 & kVbM) << (2u * kVbS));
+    const unsigned az1 = ((unsigned)k1 >> kVbS) * v.brick_slab + (((unsigned)k1 & kVbM) << (2u * kVbS));
+    const unsigned r00 = ay0 + az0, r10 = ay1 + az0, r01 = ay0 + az1, r11 = ay1 + az1;
+    c.o000 = r00 + ax0; c.o100 = r00 + ax1;
+    c.o010 = r10 + ax0; c.o110 = r10 + ax1;
+    c.o001 = r01 + ax0; c.o101 = r01 + ax1;
+    c.o011 = r11 + ax0; c.o111 = r11 + ax1;
+    return c;
+}
+
+// requests the eight corners of position q into X, returns the interpolation weights
+template <int V, typename T>
+__device__ __forceinline__ void p2_request(const DevVolume& vol, __amdgpu_buffer_rsrc_t rsrc, f3 q, T (&X)[8], float& fx, float& fy, float& fz)
+{
+    constexpr unsigned kShift = (V == V_LIGHT) ? 4u : 2u;  // bytes per element
+    const Cell c = make_cell_bricked(vol, q);
+    fx = c.fx;
+    fy = c.fy;
+    fz = c.fz;
+    const unsigned o[8] = {c.o000 << kShift, c.o100 << kShift, c.o010 << kShift, c.o110 << kShift,
+                           c.o001 << kShift, c.o101 << kShift, c.o011 << kShift, c.o111 << kShift};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if constexpr (V == V_LIGHT) X[k] = __builtin_bit_cast(vr_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o[k], 0, 0));
+        else X[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o[k], 0, 0));
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B, const PwQueue Q)
+{
+    static_assert(V == V_LIGHT || V == V_BASIC, "lit / unlit shader");
+    const MarchParams& P = B.frame[0];
+    {
+        const int n = P.tf[0].res_o + 2;  // (res_c == res_o: the host's condition)
+        for (int j = (int)threadIdx.x; j < n; j += (int)blockDim.x) {
+            float4 c = P.tf[0].color[j];
+            c.w = P.tf[0].opacity[j];
+            vr_lds_tf[j] = c;
+        }
+        __syncthreads();
+    }
+    const DevVolume& vol = P.vol[0];
+    // the gather source: the bricked vec4 voxels (lit) or the bricked density plane (unlit), as a raw buffer (< 4 GiB)
+    const __amdgpu_buffer_rsrc_t rsrc =
+        (V == V_LIGHT) ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(vol.data), 0, (int)vol.data_bytes, 0x00020000)
+                       : __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vol.a_base), 0, (int)(vol.data_bytes >> 2), 0x00020000);
+    const unsigned cls = blockIdx.x & 7u;
+    const unsigned groups = (gridDim.x - cls + 7u) >> 3;
+    const unsigned wib = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned wpb = blockDim.x >> 6;
+    const unsigned n_c = Q.n_items >> 3;
+    unsigned idx = wib * groups + (blockIdx.x >> 3);
+    const float bx0 = P.bmin[0], by0 = P.bmin[1], bz0 = P.bmin[2];
+    const float bx1 = P.bmax[0], by1 = P.bmax[1], bz1 = P.bmax[2];
+    typedef typename std::conditional<V == V_LIGHT, vr_f4, float>::type Elem;
+    while (idx < n_c) {
+        const unsigned pos = (idx << 3) | cls;
+        int lb = (int)pos;
+        if (P.order != nullptr) lb = __builtin_amdgcn_readfirstlane((int)P.order[pos]);
+        const unsigned long long t_start = wall_clock64();
+        const PixelSlot slot = map_pixel_at(P, lb, 1, 0);
+        float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        unsigned blends = 0, covered = 0, fetched = 0;
+        bool alive = false;
+        f3 p = mk3(0.0f, 0.0f, 0.0f), w = p, step = p, wstep = p;
+        int n_inside = 0;
+        if (slot.active && slot.px >= P.rect[0] && slot.px <= P.rect[2] && slot.py >= P.rect[1] && slot.py <= P.rect[3]) {
+            Ray ray = setup_ray(P, slot.px, slot.py);
+            if (ray.hit) {
+                covered = 1;
+                f3 diff = mk3(ray.end.x - ray.start.x, ray.end.y - ray.start.y, ray.end.z - ray.start.z);
+                f3 dir = normalize3s(diff);
+                float ray_len = length3s(diff);
+                if (P.fragment_mode == 1) {
+                    dst = make_float4(fabsf(dir.x), fabsf(dir.y), fabsf(dir.z), 1.0f);
+                } else if (P.fragment_mode == 2) {
+                    dst = make_float4(ray.start.x, ray.start.y, ray.start.z, 1.0f);
+                } else if (P.fragment_mode == 3) {
+                    dst = make_float4(ray.end.x, ray.end.y, ray.end.z, 1.0f);
+                } else if (P.fragment_mode == 4) {
+                    dst = make_float4(0.5f * (ray.world0.x / 1.0f) + 0.5f, -0.5f * (ray.world0.y / 1.0f) + 0.5f, 0.0f, 1.0f);
+                } else {
+                    float step_size = P.step_size;
+                    if constexpr (V == V_LIGHT) {  // CalculateWorldStep before the override
+                        wstep = mk3(dir.x * (step_size * 1.0f), dir.y * (step_size * 1.0f), dir.z * (step_size * 0.5f));
+                        wstep.z = wstep.z * (-1.0f);
+                    }
+                    if (P.toggle_varstep == 1) step_size = ray_len / (float)P.steps_count;
+                    p = ray.start;
+                    if (P.toggle_jitter == 1) {
+                        float jt = jitter((float)slot.px + 0.5f, (float)slot.py + 0.5f);
+                        p = mk3(p.x + (dir.x * step_size) * jt, p.y + (dir.y * step_size) * jt, p.z + (dir.z * step_size) * jt);
+                    }
+                    step = mk3(dir.x * step_size, dir.y * step_size, dir.z * step_size);
+                    w = ray.world0;
+                    n_inside = steps_inside(p, step, bx0, by0, bz0, bx1, by1, bz1);
+                    alive = P.steps_count > 0;
+                }
+            }
+        }
+        if (__ballot(alive) != 0) {  // (wave-uniform: from here on every lane executes every statement)
+            // The loop starts two steps EARLY (i = -2, -1: nothing is consumed, the corners of steps 0 and 1 are requested), so that
+            // the only place a buffer is written is the request inside the loop: with a prologue that loads the buffers before
+            // the loop, the values entering the loop and the values coming round the back edge are different registers, and the
+            // copies the compiler puts on the back edge need the data -- every trip ended in s_waitcnt vmcnt(0).  pr runs two
+            // steps ahead of p by the same rounded additions (pr_i = p_{i+2} exactly).
+            Elem A[8], Bq[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (V == V_LIGHT) {
+                    A[k] = vr_f4{0.0f, 0.0f, 0.0f, 0.0f};
+                    Bq[k] = vr_f4{0.0f, 0.0f, 0.0f, 0.0f};
+                } else {
+                    A[k] = 0.0f;
+                    Bq[k] = 0.0f;
+                }
+            }
+            float afx = 0.0f, afy = 0.0f, afz = 0.0f, bfx = 0.0f, bfy = 0.0f, bfz = 0.0f;
+            f3 pr = p;
+            // one step: its corners are in X (garbage for i < 0: nothing is blended then); the corners of the position two
+            // steps on are requested into X again
+            auto one_step = [&](int i, Elem (&X)[8], float& xfx, float& xfy, float& xfz) {
+                const bool in_time = alive && i >= 0 && i < P.steps_count;
+                bool inb = in_time;
+                if (i >= n_inside) inb = in_time && p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
+                v2f zw = v2f{0.0f, 0.0f}, gxy = zw;
+                TfFetch tq;
+                if constexpr (V == V_LIGHT) {
+                    Fetch4 q;
+                    q.a = make_float4(X[0].x, X[0].y, X[0].z, X[0].w); q.b = make_float4(X[1].x, X[1].y, X[1].z, X[1].w);
+                    q.d = make_float4(X[2].x, X[2].y, X[2].z, X[2].w); q.e = make_float4(X[3].x, X[3].y, X[3].z, X[3].w);
+                    q.f = make_float4(X[4].x, X[4].y, X[4].z, X[4].w); q.g = make_float4(X[5].x, X[5].y, X[5].z, X[5].w);
+                    q.h = make_float4(X[6].x, X[6].y, X[6].z, X[6].w); q.i = make_float4(X[7].x, X[7].y, X[7].z, X[7].w);
+                    zw = interp_zw(q, xfx, xfy, xfz);
+                    tq = tf_fetch_lds(P.tf[0], zw.y);
+                    gxy = interp_xy(q, xfx, xfy, xfz);
+                } else {
+                    Fetch1 q;
+                    q.a = X[0]; q.b = X[1]; q.d = X[2]; q.e = X[3]; q.f = X[4]; q.g = X[5]; q.h = X[6]; q.i = X[7];
+                    zw.y = interp_a(q, xfx, xfy, xfz);
+                    tq = tf_fetch_lds(P.tf[0], zw.y);
+                }
+                // Everything that reads the old corners must be COMPUTED here, before their registers are loaded again: left alone,
+                // the compiler sinks the gradient's interpolation into the `if (inb)` below (its only user), the old corners then
+                // live across the new loads, the new loads get other registers, and the copies that bring them back at the loop's
+                // back edge need the data (s_waitcnt vmcnt(0) every trip).
+                asm volatile("" : "+v"(zw.x), "+v"(zw.y), "+v"(gxy.x), "+v"(gxy.y));
+                __builtin_amdgcn_sched_barrier(0);  // the old corners are dead here: the new ones may land in their registers
+                p2_request<V>(vol, rsrc, pr, X, xfx, xfy, xfz);  // the corners of step i + 2
+                __builtin_amdgcn_sched_barrier(0);
+                pr = mk3(pr.x + step.x, pr.y + step.y, pr.z + step.z);
+                if (inb) {
+                    if constexpr (V == V_LIGHT) {
+                        light_shade_blend(P, w, zw, gxy, tq, dst);
+                    } else {
+                        const TfSample t = tf_finish(tq);
+                        blend(t.rgb, t.opacity, dst);
+                    }
+                    ++fetched;
+                    ++blends;
+                    if (!can_blend<V>(dst.w)) alive = false;  // cut-off reached: no later iteration can blend
+                } else if (in_time) {
+                    // p moves monotonically per component: once past the far bound it never returns
+                    const bool gone = (step.x >= 0.0f && p.x > bx1) || (step.x <= 0.0f && p.x < bx0) || (step.y >= 0.0f && p.y > by1) ||
+                                      (step.y <= 0.0f && p.y < by0) || (step.z >= 0.0f && p.z > bz1) || (step.z <= 0.0f && p.z < bz0);
+                    if (gone) alive = false;
+                }
+                if (i >= 0) {  // (wave-uniform)
+                    p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                    if constexpr (V == V_LIGHT) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                }
+            };
+            for (int i = -2; i < P.steps_count && __ballot(alive) != 0; i += 2) {
+                one_step(i, A, afx, afy, afz);
+                one_step(i + 1, Bq, bfx, bfy, bfz);
+            }
+        }
+        if (slot.active || (P.packed && slot.in_launch)) P.out[slot.out_index] = dst;
+        store_wave_counts(P, lb, blends, covered, fetched, t_start);
+        unsigned r = 0;
+        if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cls * kPwHeadStride, 1u);
+        idx = groups * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
     }
 }
 
