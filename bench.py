@@ -70,7 +70,9 @@ KERNEL_OF_FLAVOUR = {1: "march_kernel (no skipping)", 2: "march_wtb_light_kernel
                      8: "march_dp_kernel (2 lanes per ray)", 9: "march_kernel (one lane per ray, pipelined)",
                      10: "march_dp_kernel (4 lanes per ray, pipelined)", 11: "march_dp_kernel (2 lanes per ray, pipelined)",
                      12: "march_pw_kernel (persistent wavefronts, TF slot 0 in LDS)",
-                     13: "march_pw_kernel (persistent wavefronts, TF slot 0 in LDS, corner loads pipelined)"}
+                     13: "march_pw_kernel (persistent wavefronts, TF slot 0 in LDS, corner loads pipelined)",
+                     16: "march_p2_kernel (persistent wavefronts, corner loads two steps ahead, no skipping)",
+                     17: "march_p2_kernel (persistent wavefronts, corner loads two steps ahead, skipping decided ahead of the loads)"}
 
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"],
@@ -777,7 +779,7 @@ def main():
         roofline["valu"]["clock_ghz"] = round(clock_hz / 1e9, 3) if clock_hz else None
         # the vector-memory (texture addresser / L1) data path: every lane's bytes are returned at 64 B / clk / CU
         tf_bytes = {"BASIC": 40, "LIGHT": 40, "LIGHT_INSHADER": 40, "TF_CALIB": 40}.get(vname, 80)
-        if ran in (12, 13):
+        if ran in (12, 13, 16, 17):
             tf_bytes -= 40  # TF slot 0 comes from LDS
         l1_bytes = my_fetched * (bs + tf_bytes) + my_samples // 1  # + one distance-field byte per executed step (lower bound)
         l1_peak = 64.0 * 256 * clock_hz / 1e9 if clock_hz else None

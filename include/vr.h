@@ -318,8 +318,12 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *   12 / 13  persistent wavefronts (csrc/vr_pw.h): one workgroup of 16 wavefronts per CU, the packets come from a queue
  *      (eight heads, longest chains first), TF slot 0 is read from LDS; 13 also issues the next step's corner loads before
  *      this step's shading (lit / unlit shader).  Launches of one frame; fewer bytes through the texture addressers
- *   16  persistent wavefronts, NO skipping, corner loads two steps ahead (two corner buffers, 3 wavefronts per SIMD): for volumes
+ *   16  persistent wavefronts, NO skipping, corner loads two steps ahead (two corner buffers, 2 wavefronts per SIMD): for volumes
  *      with nothing to skip; lit / unlit shader with TF slot 0 in LDS and the bricked copy, else it runs as 13
+ *   17  the same with exact empty-space skipping decided ahead of the loads (one distance-field byte per ray rides along with
+ *      each corner buffer; idle rays' lanes are switched off for the loads; runs of identity steps become jumps of the requests
+ *      while the steps in flight are consumed; 3 wavefronts per SIMD); else it runs as 12.  The default for whole frames of
+ *      the lit / unlit shader whose longest ray chain is 200 .. 400 samples
  *   14  lanes per ray chosen PER PACKET (csrc/vr_mixed.h): packets whose longest ray chain in an earlier launch of the same
  *      shape reached 75 % of that launch's longest are marched as two half packets with two lanes per ray, the rest with
  *      one; one-frame launches of the shaders that have a depth-parallel form                                  */

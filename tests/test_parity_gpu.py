@@ -233,7 +233,7 @@ def test_skipping_with_hostile_values(ctx):
     tf = zero_prefix_tf(32, 3)
     for variant in (capi.BASIC, capi.LIGHT, capi.LIGHT_INSHADER):
         ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
-        for flavour in vt.flavours(0, 1, 5, 6, 8, 9, 11, 12, 13, 14, 15, 16):  # every loop form and lanes-per-ray layout
+        for flavour in vt.flavours(0, 1, 5, 6, 8, 9, 11, 12, 13, 14, 15, 16, 17):  # every loop form and lanes-per-ray layout
             ctx.set_kernel_flavour(flavour)
             frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
             assert same(frag, ref) and ns == n_ref, (variant, flavour)
@@ -368,7 +368,7 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
                 assert ctx.counters()[2] < 0.5 * ns
 
 
-@pytest.mark.parametrize("flavour", vt.flavours(4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16))
+@pytest.mark.parametrize("flavour", vt.flavours(4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17))
 def test_exact_leaping_flavour(ctx, flavour):
     """Every way of getting through empty space and every lanes-per-ray layout must reproduce the step-by-step
     accumulation bit for bit (frames AND sample counts): 5 single steps, 6 wave-uniform runs of plain additions,
@@ -393,7 +393,7 @@ def test_exact_leaping_flavour(ctx, flavour):
                 kw.update(extra)
                 u = hr.make_uniforms(W, H, **kw)
                 for variant in (capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.LIGHT_INSHADER):
-                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6, 12, 13, 15, 16):
+                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6, 12, 13, 15, 16, 17):
                         continue  # one-lane kernel only: the other flavours resolve to 6
                     vols = [v] if variant != capi.THREE_FILES else [v, vt.dose_volume()]
                     tfs = [tf] if variant != capi.THREE_FILES else [tf, vt.scene(capi.THREE_FILES, n=8)[1][1]]
@@ -406,7 +406,7 @@ def test_exact_leaping_flavour(ctx, flavour):
         ctx.set_kernel_flavour(0)
 
 
-@pytest.mark.parametrize("flavour", vt.flavours(6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16))
+@pytest.mark.parametrize("flavour", vt.flavours(6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17))
 @pytest.mark.parametrize("variant", range(8))
 def test_every_variant_every_layout(ctx, variant, flavour):
     """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
@@ -674,7 +674,7 @@ def test_fused_every_variant_every_loop_form(fused, variant):
     W, H = 70, 45
     vols, tfs = vt.scene(variant, n=24)
     step, count = hr.stepping_params(24, 24, 24)
-    for fl in vt.flavours(0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
+    for fl in vt.flavours(0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17):
         fused.set_kernel_flavour(fl)
         for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
                    dict(distance=0.7, yaw=1.0)):
@@ -694,7 +694,7 @@ def test_fused_empty_space_skipping_is_exact(fused, variant, zeros):
     for cam in (dict(yaw=0.9, pitch=-0.3), dict(yaw=-2.1, pitch=0.6, distance=0.85)):
         u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam)
         outs = []
-        for fl in vt.flavours(0, 1, 5, 11, 12, 13, 15, 16):
+        for fl in vt.flavours(0, 1, 5, 11, 12, 13, 15, 16, 17):
             fused.set_kernel_flavour(fl)
             frag, n_s = check(fused, variant, u, vols, tfs, W, H)
             outs.append((vt.bits(frag), n_s))
@@ -952,7 +952,7 @@ def test_persistent_wavefronts_queue_and_lds_table(ctx):
     resolutions (the LDS form needs one index for both: falls back to L1), every launch bit-equal to the oracle."""
     step, count = hr.stepping_params(24, 24, 24)
     try:
-      for pw in (12, 13, 16):  # 13: + the next step's corner loads pipelined; 16: no skipping, corner loads two steps ahead
+      for pw in (12, 13, 16, 17):  # 13: + the next step's corner loads pipelined; 16 / 17: corner loads two steps ahead
         ctx.set_kernel_flavour(pw)
         for W, H, kw in ((24, 16, dict()), (200, 120, dict(yaw=1.1, pitch=-0.2)), (96, 80, dict(distance=0.8))):
             for res_o, res_c in ((4096, 4096), (256, 256), (64, 128), (8190, 8190), (8191, 8191)):
@@ -962,8 +962,8 @@ def test_persistent_wavefronts_queue_and_lds_table(ctx):
                 for variant in (capi.LIGHT, capi.BASIC):
                     for _ in range(3):  # the same queue slot comes round again after eight launches
                         check(ctx, variant, u, vols, [tf], W, H)
-                    # (16 needs one table resolution and the bricked copy; it resolves to 13 otherwise)
-                    assert ctx.last_kernel_flavour() == (pw if pw != 16 or res_o == res_c and res_o <= 8190 else 13)
+                    # (16 / 17 need one table resolution and the bricked copy; they resolve to 13 / 12 otherwise)
+                    assert ctx.last_kernel_flavour() == (pw if pw < 16 or res_o == res_c and res_o <= 8190 else {16: 13, 17: 12}[pw])
         # a 1080p frame: every wavefront takes several packets; ten launches in a row, two of them without a launch order
         W, H = 1920, 1080
         vols, tfs = vt.scene(capi.LIGHT, n=24)
@@ -990,20 +990,22 @@ def test_persistent_wavefronts_block_records(ctx):
     ctx.resize(W, H)
     try:
         recs = []
-        for fl in (6, 12, 13, 16):
+        for fl in (6, 12, 13, 16, 17):
             ctx.set_kernel_flavour(fl)
             for _ in range(5):  # (from the fourth launch on the blocks are taken longest first)
                 vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
             recs.append(ctx.block_trace().astype(np.uint64))
         a = recs[0]
-        for fl, b in zip((12, 13, 16), recs[1:]):
+        for fl, b in zip((12, 13, 16, 17), recs[1:]):
             assert a.shape == b.shape and a.shape[0] > 0
             assert np.array_equal(a[:, :2], b[:, :2])                     # composited, covered per logical block
-            if fl != 16:  # (16 skips nothing: it fetches every composited sample)
+            if fl < 16:
                 assert np.array_equal(a[:, 2], b[:, 2])                   # fetched
                 assert np.array_equal(a[:, 5] >> 40, b[:, 5] >> 40)       # longest ray chain per block
-            else:
+            elif fl == 16:  # (16 skips nothing: it fetches every composited sample)
                 assert np.array_equal(b[:, 2], b[:, 0])
+            else:  # (17 skips by whole wavefronts: every ray of a packet that samples fetches)
+                assert (b[:, 2] >= a[:, 2]).all() and (b[:, 2] <= b[:, 0]).all()
             assert (b[:, 4] >= b[:, 3]).all()
     finally:
         ctx.set_kernel_flavour(0)

@@ -64,6 +64,30 @@ def main():
     rank_chain = np.argsort(np.argsort(-crit))
     print(f"rank correlation of start time with descending chain length: {np.corrcoef(rank_start, rank_chain)[0, 1]:.3f}")
     print(f"longest sample chain {crit.max()}  p99 {np.percentile(crit[heavy], 99):.0f}  median of busy workgroups {np.median(crit[heavy]):.0f}")
+    # what a packet's time is made of: duration against its longest sample chain, for packets that started while the machine
+    # was filling (first 5 % of the span: they run beside a full machine for most of their life)
+    early = heavy & ((t0 - base) / 100.0 < 0.05 * span)
+    if early.sum() > 50:
+        c, d = crit[early].astype(np.float64), dur[early]
+        A = np.stack([c, np.ones_like(c)], 1)
+        (slope, icpt), *_ = np.linalg.lstsq(A, d, rcond=None)
+        print(f"packets started in the first 5 % that fetched: {early.sum()}  duration ~ {icpt:.1f} us + {slope:.3f} us x chain")
+        qs = np.quantile(c, [0, 0.2, 0.4, 0.6, 0.8, 1.0])
+        for lo, hi in zip(qs[:-1], qs[1:]):
+            m = (c >= lo) & (c <= hi)
+            steps = tr[early, 0][m] / np.maximum(1, tr[early, 1][m])  # composited per covered pixel = steps a ray takes in the box
+            print(f"   chain {lo:4.0f}..{hi:4.0f}: n {m.sum():5d}  median duration {np.median(d[m]):6.1f} us  median steps in box per ray {np.median(steps):6.1f}"
+                  f"  us per chain step {np.median(d[m] / np.maximum(1, c[m])):.3f}")
+    if os.environ.get("VR_P2_DEBUG"):  # (a -DVR_P2_DEBUG=1 build: the fetched word holds march_p2_kernel's loop counters)
+        f = tr[:, 2]
+        trips, smp, shd, jmp = f & 0xfff, (f >> 12) & 0xfff, (f >> 24) & 0xfff, (f >> 36) & 0xfff
+        busy = smp > 0
+        for name, sel in (("all sampling packets", busy), ("duration > 350 us", busy & (dur > 350)), ("duration 200..350 us", busy & (dur > 200) & (dur <= 350))):
+            if sel.sum() == 0:
+                continue
+            print(f"[loop counters] {name}: n {sel.sum()}  median duration {np.median(dur[sel]):.0f} us  trips {np.median(trips[sel]):.0f}  sampled steps {np.median(smp[sel]):.0f}"
+                  f"  shaded steps {np.median(shd[sel]):.0f}  jumps {np.median(jmp[sel]):.0f}  chain {np.median(crit[sel]):.0f}"
+                  f"  us per trip {np.median(dur[sel] / np.maximum(1, trips[sel])):.2f}")
     # residency over time (20 bins)
     edges = np.linspace(0, span, 21)
     res = []

@@ -19,6 +19,10 @@ __global__ __launch_bounds__(1024) void issue_kernel(float* out, unsigned long l
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = v2{seed + i, seed - i};
     const v2 b = v2{seed * 0.5f, seed * 0.25f}, c = v2{1.0f - seed, seed};
+    unsigned sa[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sa[i] = __builtin_amdgcn_readfirstlane((int)seed + i);
+    unsigned long long sm = __builtin_amdgcn_read_exec();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
@@ -35,6 +39,12 @@ __global__ __launch_bounds__(1024) void issue_kernel(float* out, unsigned long l
                 if constexpr (KIND == 7) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i].x));
                 if constexpr (KIND == 8) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
                 if constexpr (KIND == 9) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i].x) : "v"(b.x));
+                // scalar instructions: alone, and one beside every vector instruction (does the scalar stream cost issue time
+                // of its own when the vector port is the busy one?)
+                if constexpr (KIND == 10) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sa[i]) : : "scc");
+                if constexpr (KIND == 11) asm volatile("v_add_f32 %0, %2, %0\n\ts_add_u32 %1, %1, 1" : "+v"(a[i].x), "+s"(sa[i]) : "v"(b.x) : "scc");
+                if constexpr (KIND == 12) asm volatile("v_add_f32 %0, %2, %0\n\tv_add_f32 %0, %2, %0\n\ts_add_u32 %1, %1, 1" : "+v"(a[i].x), "+s"(sa[i]) : "v"(b.x) : "scc");
+                if constexpr (KIND == 13) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\ts_and_b64 %2, vcc, exec" : : "v"(a[i].x), "v"(b.x), "s"(sm) : "vcc", "scc");
             }
         }
     }
@@ -42,7 +52,9 @@ __global__ __launch_bounds__(1024) void issue_kernel(float* out, unsigned long l
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a[i].x + a[i].y;
-    if (s == 12345.678f) out[0] = s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += (float)sa[i];
+    if (s == 12345.678f) out[0] = s + (float)sm;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
@@ -54,7 +66,7 @@ int run(const char* name, int cus)
     CHECK(hipMalloc(&out, 16));
     CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * 256 * 32 * 2));
     printf("%-16s", name);
-    for (int wps : {1, 2, 4, 5, 8}) {   // wavefronts per SIMD: one workgroup of wps * 4 wavefronts per CU
+    for (int wps : {1, 2, 3, 4, 5, 8}) {   // wavefronts per SIMD: one workgroup of wps * 4 wavefronts per CU
         const int threads = wps * 4 * 64;
         const int block = threads > 1024 ? threads / 2 : threads, per_cu = threads > 1024 ? 2 : 1;
         hipEvent_t e0, e1;
@@ -99,5 +111,9 @@ int main()
     run<7>("v_rcp_f32", cus);
     run<8>("v_med3_f32", cus);
     run<9>("v_mov_b32", cus);
+    run<10>("s_add_u32", cus);
+    run<11>("v_add+s_add", cus);     // (per PAIR of instructions)
+    run<12>("2 v_add+s_add", cus);   // (per TRIPLE)
+    run<13>("v_cmp+s_and", cus);     // (per pair)
     return 0;
 }

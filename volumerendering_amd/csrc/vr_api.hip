@@ -134,6 +134,7 @@ struct vr_ctx {
     bool last_otf = false;    // ... and whether it derived the gradients from the density plane
     int xcd_mode = 1;         // deal a tile's workgroups over the XCDs (VR_EXP_XCD=0: one XCD per tile)
     bool pw_ltf = true;       // persistent wavefronts keep TF slot 0 in LDS (VR_EXP_PW_LTF=0: from L1, for A/B)
+    unsigned p2_threads = 0;  // flavours 16 / 17: threads per workgroup when not 768 (VR_EXP_P2_THREADS: fewer wavefronts per CU)
     bool pw_steal = false;    // ... and take other classes' packets once their own class is exhausted (VR_EXP_PW_STEAL=1: measured
                               // 2-4 % slower -- the classes are even when a tile's packets are dealt over them)
     double active_fraction = 1.0;  // share of bricks that are not inert, of the distance field in use
@@ -424,12 +425,16 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
     }
     // persistent wavefronts (12; vr_pw.h) exist for launches of one frame
-    if ((fl == 12 || fl == 13 || fl == 16) && n_frames != 1) fl = 6;
-    // two steps ahead (16; march_p2_kernel): lit / unlit shader, TF slot 0 in LDS, the bricked copy below 4 GiB; else 13
-    if (fl == 16 && !((variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC) && c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c &&
-                      c->tf[0].res_o + 2 <= 8192 && c->layout_mode == 0 && c->vol_bricked[0] && c->vol_bdens[0] && off32 &&
-                      (size_t)c->vol_bricked_cap[0] * 16 <= 0xFFFFFFFFull))
-        fl = 13;
+    if ((fl == 12 || fl == 13 || fl == 16 || fl == 17) && n_frames != 1) fl = 6;
+    // two steps ahead (16, 17; march_p2_kernel): lit / unlit shader, TF slot 0 in LDS, the bricked copy below 4 GiB with rows and
+    // slabs of bricks below 2^24 slots (make_cell_bricked's 24-bit multiplies); else 13 / 12
+    bool p2_ok = (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC) && c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c &&
+                 c->tf[0].res_o + 2 <= 8192 && c->layout_mode == 0 && c->vol_bricked[0] && c->vol_bdens[0] && off32 && n_frames == 1;
+    if (p2_ok) {
+        const size_t nbx = ((unsigned)c->vol[0].nx + kVbM) >> kVbS, nby = ((unsigned)c->vol[0].ny + kVbM) >> kVbS, nbz = ((unsigned)c->vol[0].nz + kVbM) >> kVbS;
+        p2_ok = nbx * nby * nbz * kVbN * 16 <= 0xFFFFFFFFull && nbx * nby * kVbN < (1u << 24);
+    }
+    if ((fl == 16 || fl == 17) && !p2_ok) fl = fl == 16 ? 13 : 12;
     // LDS tiles (15; vr_lt.h): the lit shader, launches of one frame
     if (fl == 15 && (n_frames != 1 || variant != VR_VARIANT_LIGHT)) fl = 6;
     // mixed lanes per ray (14; vr_mixed.h): launches of one frame, shaders that have a depth-parallel form
@@ -529,11 +534,12 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const bool whole_frame = (double)px_all / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 4.5;
         const bool nothing_to_skip = !can_skip || c->active_fraction >= 0.9;
         // (16 = the no-skip kernel with the corner loads two steps ahead, when TF slot 0 fits LDS and the bricked copy is in
-        // use: noisy air 2.60 -> 2.16 ms; 13 otherwise)
-        if (whole_frame && nothing_to_skip)
-            fl = (c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c && c->tf[0].res_o + 2 <= 8192 && c->layout_mode == 0 && c->vol_bricked[0] &&
-                  c->vol_bdens[0] && (size_t)c->vol_bricked_cap[0] * 16 <= 0xFFFFFFFFull) ? 16 : 13;
+        // use: noisy air 2.60 -> 2.04 ms; 13 otherwise)
+        if (whole_frame && nothing_to_skip) fl = p2_ok ? 16 : 13;
         else if (whole_frame && chain_known >= 400u + 1u) fl = 12;
+        // (17 = two steps ahead with the skipping decided ahead of the loads: C3's default table 0.644 -> 0.610 ms; it loses where
+        // the chains are short -- C2, longest chain 102: 0.111 -> 0.161 -- and to 12 where they are longest -- thin: 0.704 / 0.782)
+        else if (whole_frame && p2_ok && can_skip && chain_known >= 200u + 1u) fl = 17;
         c->last_flavour = fl;
     }
 
@@ -574,7 +580,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // one wavefront per workgroup (launch order at wavefront granularity) -- except for the depth-parallel kernels on
         // large launches, where 4x the workgroups cost more at dispatch than the finer order gains (C2: 32 768 workgroups of
         // a 0.12 ms frame)
-        const bool pw = fl == 12 || fl == 13 || fl == 16;
+        const bool pw = fl == 12 || fl == 13 || fl == 16 || fl == 17;
         if (pw && c->pw_xcd_mode >= 0) P.xcd_mode = c->pw_xcd_mode;
         int wpb = wtb ? 4 : ((pw || fl == 15) ? 1 : c->waves_per_block);
         if (dp && P.n_tiles * (dp == 4 ? 256 : 128) > 16384) wpb = 4;
@@ -659,6 +665,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.pw_ltf = false;
             L.pw_pipe = false;
             L.pw_p2 = false;
+            L.pw_p2_skip = false;
             L.lds_bytes = 0;
             L.queue = PwQueue{nullptr, 0u, 0u};
             L.mixed_items = nullptr;
@@ -683,12 +690,16 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 // persistent wavefronts: `grid` stays the number of LOGICAL blocks (records, launch order); the launch itself is one
                 // workgroup of 16 wavefronts per CU (fewer when there are fewer packets), TF slot 0 in LDS when its two tables
                 // have one resolution and fit beside nothing else (R <= 8190: 128 KiB)
-                const unsigned pw_threads = fl == 16 ? 768u : 1024u;  // (march_p2_kernel: two corner buffers, 3 wavefronts per SIMD)
+                // (march_p2_kernel: two corner buffers, 3 wavefronts per SIMD at most; with every ray sampling all the time two per
+                // SIMD are faster -- the corner data in flight is many times the L1 either way: noisy air 2.13 -> 2.04 ms)
+                unsigned pw_threads = fl == 17 ? 768u : (fl == 16 ? 512u : 1024u);
+                if ((fl == 16 || fl == 17) && c->p2_threads) pw_threads = c->p2_threads;  // (VR_EXP_P2_THREADS: 64 .. 768)  // (march_p2_kernel: two corner buffers, 3 wavefronts per SIMD)
                 const unsigned per_wg = pw_threads / 64u;
                 const unsigned wgs = (grid.x + per_wg - 1u) / per_wg;
                 L.pw = true;
                 L.pw_pipe = fl == 13;
-                L.pw_p2 = fl == 16;
+                L.pw_p2 = fl == 16 || fl == 17;
+                L.pw_p2_skip = fl == 17 && P.brick_dist != nullptr;
                 L.pw_ltf = c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c && c->tf[0].res_o + 2 <= 8192;
                 L.lds_bytes = L.pw_ltf ? (unsigned)(c->tf[0].res_o + 2) * 16u : 0u;
                 L.queue.heads = c->d_pw_heads + (size_t)cb * 8 * 64;
@@ -1028,6 +1039,10 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
     if (const char* e = getenv("VR_EXP_PW_STEAL")) c->pw_steal = atoi(e) != 0;
+    if (const char* e = getenv("VR_EXP_P2_THREADS")) {
+        const int t = atoi(e);
+        if (t >= 64 && t <= 768 && t % 64 == 0) c->p2_threads = (unsigned)t;
+    }
     if (const char* e = getenv("VR_EXP_PW_POLICY")) c->pw_policy = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_XCD")) c->pw_xcd_mode = atoi(e);
     if (!hip_ok(hipMalloc(&c->d_pw_heads, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMalloc(queue heads)")) return bail(VR_ERR_HIP);
@@ -1654,7 +1669,7 @@ int vr_volume_layout(vr_ctx* c, int slot, int* flags)
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 16) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 17) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     if (!VR_EXPERIMENTAL_FLAVOURS && (flavour == 2 || flavour == 3 || flavour == 4 || flavour == 5 || flavour == 9))
         return fail(c, VR_ERR_UNSUPPORTED, "vr_set_kernel_flavour: flavours 2, 3, 4, 5 and 9 are compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
     c->flavour = flavour;

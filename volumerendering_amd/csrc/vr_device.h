@@ -147,6 +147,7 @@ struct LaunchDesc {
     bool pw_ltf;      // ... with TF slot 0 in LDS (lds_bytes of dynamic LDS)
     bool pw_pipe;     // ... with the next step's corner loads software-pipelined (lit / unlit shader)
     bool pw_p2;       // ... the no-skip form with the corner loads two steps ahead (march_p2_kernel; TF slot 0 in LDS, bricked copy)
+    bool pw_p2_skip;  // ... ... with skipping by whole wavefronts (march_p2_kernel<V, true>)
     unsigned lds_bytes;
     PwQueue queue;
     const unsigned* mixed_items;  // lanes per ray chosen per packet (vr_mixed.h): the item list, grid = its positions

@@ -488,9 +488,14 @@ __device__ __forceinline__ v2f lerp2(v2f a, v2f b, float t) { return mad2(b - a,
 // instructions on a register pair (8 of the 32 instructions of two separate calls saved: the lit shader normalises the
 // gradient and the light direction in every sample, and the kernel sits on the vector-ALU issue limit).  The generic
 // operators when either argument is outside [2^-60, 2^60).
+// UNI: the choice is made once for the wavefront (the generic operators for every lane when any lane needs them: same bits,
+// one scalar branch instead of two exec-mask regions -- for loops that count their scalar instructions, vr_pw.h).
+template <bool UNI = false>
 __device__ __forceinline__ v2f inv_sqrt_exact2(float a, float b)
 {
-    if ((__float_as_uint(a) - 0x21800000u < 0x3c000000u) && (__float_as_uint(b) - 0x21800000u < 0x3c000000u)) {
+    bool in_range = (__float_as_uint(a) - 0x21800000u < 0x3c000000u) && (__float_as_uint(b) - 0x21800000u < 0x3c000000u);
+    if constexpr (UNI) in_range = __ballot(!in_range) == 0;
+    if (in_range) {
         const v2f x = v2f{a, b};
         v2f y = v2f{__builtin_amdgcn_sqrtf(a), __builtin_amdgcn_sqrtf(b)};
         const v2f yd = v2f{__int_as_float(__float_as_int(y.x) - 1), __int_as_float(__float_as_int(y.y) - 1)};
@@ -936,15 +941,16 @@ __device__ __forceinline__ bool opacity_is_zero(const MarchParams& P, float d)
 // The lit shader from the interpolated voxel to the blend (BasicVolLightApp.wgsl:216-223), on (x, y) / (r, g) register pairs
 // so that the packed instructions need no shuffling; per component the operations and their order are those of
 // normalize3 / shade / blend.  zw = (gradient z, density), gxy = (gradient x, gradient y), tq = the table texels of `density`.
+template <bool UNI = false>
 __device__ __forceinline__ void light_shade_blend(const MarchParams& P, f3 w, v2f zw, v2f gxy, const TfFetch& tq, float4& dst)
 {
     v2f Lxy = v2f{P.light_pos[0] - w.x, P.light_pos[1] - w.y};
     float Lz = P.light_pos[2] - w.z;
 #if VR_FUSED
-    const v2f inv = inv_sqrt_exact2(mad(zw.x, zw.x, mad(gxy.y, gxy.y, gxy.x * gxy.x)), mad(Lz, Lz, mad(Lxy.y, Lxy.y, Lxy.x * Lxy.x)));
+    const v2f inv = inv_sqrt_exact2<UNI>(mad(zw.x, zw.x, mad(gxy.y, gxy.y, gxy.x * gxy.x)), mad(Lz, Lz, mad(Lxy.y, Lxy.y, Lxy.x * Lxy.x)));
 #else
     const v2f g2 = gxy * gxy, l2 = Lxy * Lxy;
-    const v2f inv = inv_sqrt_exact2((g2.x + g2.y) + zw.x * zw.x, (l2.x + l2.y) + Lz * Lz);
+    const v2f inv = inv_sqrt_exact2<UNI>((g2.x + g2.y) + zw.x * zw.x, (l2.x + l2.y) + Lz * Lz);
 #endif
     const float inv_g = inv.x, inv_l = inv.y;  // (the two normalisations' 1 / length, computed side by side)
     const v2f Nxy = gxy * inv_g;

@@ -119,16 +119,23 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
     } while (0)
     constexpr bool kCanPipe = (V == V_BASIC || V == V_LIGHT);
     if constexpr (kCanPipe) {
-        if (L.pw_p2) {  // two steps ahead, no skipping (the host: TF slot 0 in LDS, bricked copy below 4 GiB)
-            auto k = march_p2_kernel<V>;
-            if (L.lds_bytes > 48u * 1024u) {
-                static unsigned raised = 0;
-                if (L.lds_bytes > raised) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
-                    raised = L.lds_bytes;
-                }
-            }
-            hipLaunchKernelGGL(k, L.grid, L.block, L.lds_bytes, s, B, L.queue);
+        if (L.pw_p2) {  // two steps ahead (the host: TF slot 0 in LDS, bricked copy below 4 GiB); skipping by whole wavefronts
+#define VR_LAUNCH_P2(S)                                                                                                \
+    do {                                                                                                               \
+        auto k = march_p2_kernel<V, S>;                                                                                \
+        if (L.lds_bytes > 48u * 1024u) {                                                                               \
+            static unsigned raised = 0;                                                                                \
+            if (L.lds_bytes > raised) {                                                                                \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,\
+                                          (int)L.lds_bytes);                                                           \
+                raised = L.lds_bytes;                                                                                  \
+            }                                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(k, L.grid, L.block, L.lds_bytes, s, B, L.queue);                                            \
+    } while (0)
+            if (skip && L.pw_p2_skip) VR_LAUNCH_P2(true);
+            else VR_LAUNCH_P2(false);
+#undef VR_LAUNCH_P2
             return;
         }
     }

@@ -91,16 +91,16 @@ __global__ __launch_bounds__(kPwThreads) void march_pw_kernel(const MarchBatch B
     }
 }
 
-// ---- two steps ahead: the no-skip form (flavour 16) ---------------------------------------------------------------
+// ---- two steps ahead (flavours 16 and 17) ------------------------------------------------------------------------
 // Everything in a step but the blend is independent of the step before (positions are known in advance), so the remedy for a
 // frame made of latencies is a deeper software pipeline: two corner buffers (A = even steps, B = odd steps, the loop unrolled by
 // two so that which registers hold which step is static), the corners of step i + 2 requested as soon as step i's have been
-// interpolated, table texels from LDS.  Built for the regime that is nothing but sampling (no distance field, no runs, no vote:
-// the host picks it for volumes with nothing to skip): every ray samples from its entry into the box to its cut-off or exit.
+// interpolated, table texels from LDS.  16 = every ray samples from its entry into the box to its cut-off or exit (the host
+// picks it for volumes with nothing to skip); 17 = with empty-space skipping decided ahead of the loads (SKIP, below).
 // Speculative loads of positions a ray never reaches read clamped, valid voxels and are dropped.  The loads are raw buffer
-// loads the compiler tracks (it places the s_waitcnt); kP2Threads keeps the register budget wide enough (256 VGPRs) that the
+// loads the compiler tracks (it places the s_waitcnt); kP2Threads keeps the register budget wide enough (168 VGPRs) that the
 // allocator has no reason to move a buffer while its loads are in flight.  Arithmetic per sample: light_shade_blend / blend.
-constexpr int kP2Threads = 768;  // 12 wavefronts per CU, 3 per SIMD (165 VGPRs: two corner buffers are 64 of them)
+constexpr int kP2Threads = 768;  // at most 12 wavefronts per CU, 3 per SIMD (163 - 168 VGPRs: two corner buffers are 64 of them)
 
 // Branch-free cell of a BRICKED volume: clamp-to-edge texel pairs on every axis, separable index (make_cell's arithmetic
 // without its wave-uniform fast paths: a branch between address arithmetic and loads defeats the wait-count pass).
@@ -117,10 +117,11 @@ __device__ __forceinline__ Cell make_cell_bricked(const DevVolume& v, f3 p)
     texel_pair(y0, v.ny, j0, j1);
     texel_pair(z0, v.nz, k0, k1);
     const unsigned ax0 = ((unsigned)i0 >> kVbS) * kVbN + ((unsigned)i0 & kVbM), ax1 = ((unsigned)i1 >> kVbS) * kVbN + ((unsigned)i1 & kVbM);
-    const unsigned ay0 = ((unsigned)j0 >> kVbS) * v.brick_row + (((unsigned)j0 & kVbM) << kVbS);
-    const unsigned ay1 = ((unsigned)j1 >> kVbS) * v.brick_row + (((unsigned)j1 & kVbM) << kVbS);
-    const unsigned az0 = ((unsigned)k0 >> kVbS) * v.brick_slab + (((unsigned)k0 & kVbM) << (2u * kVbS));
-    const unsigned az1 = ((unsigned)k1 >> kVbS) * v.brick_slab + (((unsigned)k1 & kVbM) << (2u * kVbS));
+    // (24-bit multiplies -- full rate, the 32-bit one is a quarter -- : the host keeps brick_row and brick_slab below 2^24)
+    const unsigned ay0 = __umul24((unsigned)j0 >> kVbS, v.brick_row) + (((unsigned)j0 & kVbM) << kVbS);
+    const unsigned ay1 = __umul24((unsigned)j1 >> kVbS, v.brick_row) + (((unsigned)j1 & kVbM) << kVbS);
+    const unsigned az0 = __umul24((unsigned)k0 >> kVbS, v.brick_slab) + (((unsigned)k0 & kVbM) << (2u * kVbS));
+    const unsigned az1 = __umul24((unsigned)k1 >> kVbS, v.brick_slab) + (((unsigned)k1 & kVbM) << (2u * kVbS));
     const unsigned r00 = ay0 + az0, r10 = ay1 + az0, r01 = ay0 + az1, r11 = ay1 + az1;
     c.o000 = r00 + ax0; c.o100 = r00 + ax1;
     c.o010 = r10 + ax0; c.o110 = r10 + ax1;
@@ -129,25 +130,50 @@ __device__ __forceinline__ Cell make_cell_bricked(const DevVolume& v, f3 p)
     return c;
 }
 
-// requests the eight corners of position q into X, returns the interpolation weights
-template <int V, typename T>
-__device__ __forceinline__ void p2_request(const DevVolume& vol, __amdgpu_buffer_rsrc_t rsrc, f3 q, T (&X)[8], float& fx, float& fy, float& fz)
+// requests the eight corners of position q into X, returns the interpolation weights.  MASKED: the lanes that say `idle`
+// request nothing.
+template <int V, bool MASKED = false, typename T>
+__device__ __forceinline__ void p2_request(const DevVolume& vol, __amdgpu_buffer_rsrc_t rsrc, f3 q, T (&X)[8], float& fx, float& fy, float& fz,
+                                           bool idle = false)
 {
     constexpr unsigned kShift = (V == V_LIGHT) ? 4u : 2u;  // bytes per element
     const Cell c = make_cell_bricked(vol, q);
     fx = c.fx;
     fy = c.fy;
     fz = c.fz;
-    const unsigned o[8] = {c.o000 << kShift, c.o100 << kShift, c.o010 << kShift, c.o110 << kShift,
-                           c.o001 << kShift, c.o101 << kShift, c.o011 << kShift, c.o111 << kShift};
+    unsigned o[8] = {c.o000 << kShift, c.o100 << kShift, c.o010 << kShift, c.o110 << kShift,
+                     c.o001 << kShift, c.o101 << kShift, c.o011 << kShift, c.o111 << kShift};
+    // The idle lanes are switched off for the eight loads by hand: the compiler does not see a branch (so it keeps no execz jump
+    // and the wait counts stay exact), the texture addresser does not see the lanes.  Nothing but the loads runs in between:
+    // the offsets are pinned into registers first, and the scheduler is fenced on both sides.
+    unsigned long long exec_saved = 0;
+    if constexpr (MASKED) {
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]));
+        const unsigned long long keep = __ballot(!idle);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1" : "=&s"(exec_saved) : "s"(keep) : "scc");
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if constexpr (V == V_LIGHT) X[k] = __builtin_bit_cast(vr_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o[k], 0, 0));
         else X[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o[k], 0, 0));
     }
+    if constexpr (MASKED) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_mov_b64 exec, %0" : : "s"(exec_saved));
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
-template <int V>
+// SKIP: empty-space skipping on top of it.  One distance-field byte per ray rides along with each corner buffer: the byte of
+// the exact position whose corners are in flight, asked for just ahead of them and read a trip later.  It says whether the
+// step blends (an inert brick: the identity, march_packet's test), whether the two steps after it need their corners at all
+// (three bricks from anything active: the requests get offsets out of range), and how many steps after it every ray of the
+// packet can skip: then the REQUESTS jump (4 .. 64 rounded additions, the identity steps of march_packet's runs) while the two
+// steps already in flight are still being consumed -- nothing in flight is thrown away and no latency is exposed.  A step in
+// which no ray blends interpolates nothing; the per-step vote (every opacity zero for certain: no texels, no gradient, no
+// shading) is march_packet's.
+template <int V, bool SKIP>
 __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B, const PwQueue Q)
 {
     static_assert(V == V_LIGHT || V == V_BASIC, "lit / unlit shader");
@@ -183,6 +209,9 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
         const PixelSlot slot = map_pixel_at(P, lb, 1, 0);
         float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         unsigned blends = 0, covered = 0, fetched = 0;
+#if VR_P2_DEBUG
+        unsigned dbg_trips = 0, dbg_sampled = 0, dbg_shaded = 0, dbg_jumps = 0;
+#endif
         bool alive = false;
         f3 p = mk3(0.0f, 0.0f, 0.0f), w = p, step = p, wstep = p;
         int n_inside = 0;
@@ -221,11 +250,18 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             }
         }
         if (__ballot(alive) != 0) {  // (wave-uniform: from here on every lane executes every statement)
-            // The loop starts two steps EARLY (i = -2, -1: nothing is consumed, the corners of steps 0 and 1 are requested), so that
-            // the only place a buffer is written is the request inside the loop: with a prologue that loads the buffers before
-            // the loop, the values entering the loop and the values coming round the back edge are different registers, and the
-            // copies the compiler puts on the back edge need the data -- every trip ended in s_waitcnt vmcnt(0).  pr runs two
-            // steps ahead of p by the same rounded additions (pr_i = p_{i+2} exactly).
+            // A wavefront issues its instructions in order, one at a time: about 5 cycles a vector instruction, 8 a scalar one, 29
+            // a compare whose mask a scalar instruction combines (tools/ubench/valu_issue.hip, 3 wavefronts per SIMD) -- with the
+            // loads two steps ahead the loop's own instruction stream is the step's latency, and mask logic is its dearest part.
+            // Hence: no per-step bookkeeping that a trip (two steps) can do once, the box test only for the last steps of a packet
+            // (tail: behind a scalar branch), wave-uniform choices wherever the result is the same.
+            //
+            // Two corner buffers: A = even steps, Bq = odd steps of a trip, the loop unrolled by two so that which registers hold
+            // which step is static; a buffer is written by requests inside the loop only (no prologue that loads them: the
+            // values entering the loop and the values coming round the back edge would be different registers, and the copies on
+            // the back edge need the data -- every trip ended in s_waitcnt vmcnt(0)).  pA / pB are the positions whose corners
+            // are in flight into A / Bq, each one rounded addition of `step` after the other: the positions the shader's loop
+            // has at those steps, exactly.
             Elem A[8], Bq[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -238,67 +274,176 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 }
             }
             float afx = 0.0f, afy = 0.0f, afz = 0.0f, bfx = 0.0f, bfy = 0.0f, bfz = 0.0f;
-            f3 pr = p;
-            // one step: its corners are in X (garbage for i < 0: nothing is blended then); the corners of the position two
-            // steps on are requested into X again
-            auto one_step = [&](int i, Elem (&X)[8], float& xfx, float& xfy, float& xfz) {
-                const bool in_time = alive && i >= 0 && i < P.steps_count;
-                bool inb = in_time;
-                if (i >= n_inside) inb = in_time && p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
-                v2f zw = v2f{0.0f, 0.0f}, gxy = zw;
+            f3 pA = p, pB = p;
+            int i = 0;  // the step pA is at (wave-uniform)
+            // steps every marching ray of the packet is certainly in time and inside the box for (wave-uniform): before that
+            // step no ray needs the box test
+            int n_in_w;
+            {
+                int v = alive ? min(n_inside, P.steps_count) : 0x7fffffff;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+                n_in_w = __builtin_amdgcn_readfirstlane(v);
+            }
+            unsigned DA = 0, DB = 0;  // the distance-field bytes of the bricks of pA and pB (0 = active, n = n bricks from an active one)
+            float leap_c = 0.0f;
+            int lim = 0;
+            if constexpr (SKIP) {
+                // steps a ray at distance-field value D can take while it certainly stays within D-1 bricks of its brick on every
+                // axis (march_packet's kRun); jumps stay inside the provably-in-box prefix of the ray
+                const float vmax = fmaxf(fmaxf(fabsf(step.x) * P.bsx, fabsf(step.y) * P.bsy), fabsf(step.z) * P.bsz);
+                leap_c = 0.999f / vmax;
+                lim = min(n_inside, P.steps_count);
+            }
+            bool idle_a = false, idle_b = false;      // this trip: step A / B blends nothing
+            bool idle_ra = false, idle_rb = false;    // ... requests nothing
+            bool tail = false;                        // this trip's steps need the box test (wave-uniform)
+            int mw = 0;                               // identity steps skipped between this trip's two steps and the next trip's
+            // consumes the corners in X (of position pX, step ix), then requests into X the corners of pY + step [+ mw steps], which
+            // becomes pX
+            auto one_step = [&](Elem (&X)[8], float& xfx, float& xfy, float& xfz, f3& pX, const f3& pY, int ix, int jump, bool idle_con, bool idle_rq, unsigned& DX) {
+                bool inb = alive, in_time = alive;
+                if (tail) {
+                    in_time = alive && ix < P.steps_count;
+                    inb = in_time && (ix < n_inside || (pX.x >= bx0 && pX.x <= bx1 && pX.y >= by0 && pX.y <= by1 && pX.z >= bz0 && pX.z <= bz1));
+                }
+                const bool sampled = SKIP ? (inb && !idle_con) : inb;
+                v2f zw = v2f{0.0f, 0.0f}, gxy;
                 TfFetch tq;
-                if constexpr (V == V_LIGHT) {
+                // (wave-uniform) a step in which no ray samples interpolates nothing
+                bool shaded = !SKIP || __ballot(sampled) != 0;
+#if VR_P2_DEBUG
+                if (shaded) ++dbg_sampled;
+#endif
+                if (!shaded) {
+                } else if constexpr (V == V_LIGHT) {
                     Fetch4 q;
                     q.a = make_float4(X[0].x, X[0].y, X[0].z, X[0].w); q.b = make_float4(X[1].x, X[1].y, X[1].z, X[1].w);
                     q.d = make_float4(X[2].x, X[2].y, X[2].z, X[2].w); q.e = make_float4(X[3].x, X[3].y, X[3].z, X[3].w);
                     q.f = make_float4(X[4].x, X[4].y, X[4].z, X[4].w); q.g = make_float4(X[5].x, X[5].y, X[5].z, X[5].w);
                     q.h = make_float4(X[6].x, X[6].y, X[6].z, X[6].w); q.i = make_float4(X[7].x, X[7].y, X[7].z, X[7].w);
                     zw = interp_zw(q, xfx, xfy, xfz);
-                    tq = tf_fetch_lds(P.tf[0], zw.y);
-                    gxy = interp_xy(q, xfx, xfy, xfz);
+                    // (the per-step vote of sample_and_blend: when every ray's opacity is zero for certain, the texels, the
+                    // gradient and the shading are left out -- the blend would be the identity)
+                    if constexpr (SKIP) shaded = __ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
+                    if (shaded) {
+                        tq = tf_fetch_lds(P.tf[0], zw.y);
+                        gxy = interp_xy(q, xfx, xfy, xfz);
+                    }
                 } else {
                     Fetch1 q;
                     q.a = X[0]; q.b = X[1]; q.d = X[2]; q.e = X[3]; q.f = X[4]; q.g = X[5]; q.h = X[6]; q.i = X[7];
                     zw.y = interp_a(q, xfx, xfy, xfz);
-                    tq = tf_fetch_lds(P.tf[0], zw.y);
+                    if constexpr (SKIP) shaded = __ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
+                    if (shaded) tq = tf_fetch_lds(P.tf[0], zw.y);
                 }
+                // the position of the next request into X.  (Only now: the box test above read pX.)
+                const f3 gone_p = pX;  // (the position this step was at: the tail's test below)
+                pX = mk3(pY.x + step.x, pY.y + step.y, pY.z + step.z);
+                for (int k = 0; k < jump; ++k) pX = mk3(pX.x + step.x, pX.y + step.y, pX.z + step.z);
                 // Everything that reads the old corners must be COMPUTED here, before their registers are loaded again: left alone,
-                // the compiler sinks the gradient's interpolation into the `if (inb)` below (its only user), the old corners then
-                // live across the new loads, the new loads get other registers, and the copies that bring them back at the loop's
-                // back edge need the data (s_waitcnt vmcnt(0) every trip).
-                asm volatile("" : "+v"(zw.x), "+v"(zw.y), "+v"(gxy.x), "+v"(gxy.y));
+                // the compiler sinks the gradient's interpolation into the `if (sampled)` below (its only user), the old corners
+                // then live across the new loads, the new loads get other registers, and the copies that bring them back at the
+                // loop's back edge need the data (s_waitcnt vmcnt(0) every trip).
+                if constexpr (V == V_LIGHT) asm volatile("" : "+v"(zw.x), "+v"(zw.y), "+v"(gxy.x), "+v"(gxy.y));
+                else asm volatile("" : "+v"(zw.y));
                 __builtin_amdgcn_sched_barrier(0);  // the old corners are dead here: the new ones may land in their registers
-                p2_request<V>(vol, rsrc, pr, X, xfx, xfy, xfz);  // the corners of step i + 2
+                // the byte of the position requested: the next trip decides with it (asked for ahead of the corner loads)
+                if constexpr (SKIP) DX = dist_at(P, brick_of<true>(P, pX));
+                p2_request<V, SKIP>(vol, rsrc, pX, X, xfx, xfy, xfz, SKIP && (idle_rq || !alive));
                 __builtin_amdgcn_sched_barrier(0);
-                pr = mk3(pr.x + step.x, pr.y + step.y, pr.z + step.z);
-                if (inb) {
-                    if constexpr (V == V_LIGHT) {
-                        light_shade_blend(P, w, zw, gxy, tq, dst);
-                    } else {
-                        const TfSample t = tf_finish(tq);
-                        blend(t.rgb, t.opacity, dst);
+#if VR_P2_DEBUG
+                if (shaded) ++dbg_shaded;
+#endif
+                if (sampled) {
+                    if (shaded) {
+                        if constexpr (V == V_LIGHT) {
+                            light_shade_blend<true>(P, w, zw, gxy, tq, dst);
+                        } else {
+                            const TfSample t = tf_finish(tq);
+                            blend(t.rgb, t.opacity, dst);
+                        }
                     }
                     ++fetched;
-                    ++blends;
-                    if (!can_blend<V>(dst.w)) alive = false;  // cut-off reached: no later iteration can blend
-                } else if (in_time) {
-                    // p moves monotonically per component: once past the far bound it never returns
-                    const bool gone = (step.x >= 0.0f && p.x > bx1) || (step.x <= 0.0f && p.x < bx0) || (step.y >= 0.0f && p.y > by1) ||
-                                      (step.y <= 0.0f && p.y < by0) || (step.z >= 0.0f && p.z > bz1) || (step.z <= 0.0f && p.z < bz0);
-                    if (gone) alive = false;
                 }
-                if (i >= 0) {  // (wave-uniform)
-                    p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
-                    if constexpr (V == V_LIGHT) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                if (inb) ++blends;
+                // cut-off reached: no later step can blend (dst.w changes in a sampled step only: the test is the loop's own)
+                alive = alive && can_blend<V>(dst.w);
+                if (tail) {
+                    if (in_time && !inb) {
+                        // a position moves monotonically per component: once past the far bound it never returns
+                        const bool gone = (step.x >= 0.0f && gone_p.x > bx1) || (step.x <= 0.0f && gone_p.x < bx0) || (step.y >= 0.0f && gone_p.y > by1) ||
+                                          (step.y <= 0.0f && gone_p.y < by0) || (step.z >= 0.0f && gone_p.z > bz1) || (step.z <= 0.0f && gone_p.z < bz0);
+                        if (gone) alive = false;
+                    }
                 }
+                if constexpr (V == V_LIGHT) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
             };
-            for (int i = -2; i < P.steps_count && __ballot(alive) != 0; i += 2) {
-                one_step(i, A, afx, afy, afz);
-                one_step(i + 1, Bq, bfx, bfy, bfz);
+            bool start = true;  // (wave-uniform) nothing is in flight yet
+#if VR_P2_DEBUG
+            dbg_trips = dbg_sampled = dbg_shaded = dbg_jumps = 0;
+#endif
+            while (i < P.steps_count && __ballot(alive) != 0) {
+                if (start) {
+                    // the bytes of pA and pB and, without waiting for them, the corners of steps 0 and 1 of every ray
+                    pB = mk3(pA.x + step.x, pA.y + step.y, pA.z + step.z);
+                    if constexpr (SKIP) {
+                        DA = dist_at(P, brick_of<true>(P, pA));
+                        DB = dist_at(P, brick_of<true>(P, pB));
+                    }
+                    p2_request<V, SKIP>(vol, rsrc, pA, A, afx, afy, afz, SKIP && !alive);
+                    p2_request<V, SKIP>(vol, rsrc, pB, Bq, bfx, bfy, bfz, SKIP && !alive);
+                    start = false;
+                }
+                mw = 0;
+                if constexpr (SKIP) {
+                    // The bytes are those of the rays' exact positions: a step in an inert brick (byte >= 1) is the identity and
+                    // blends nothing (march_packet's test); a trip in which no ray blends interpolates nothing.  Decided AHEAD of the
+                    // loads, from the number of steps after pB a ray certainly spends in inert bricks: a ray requests nothing for
+                    // a position it reaches within them (its lanes are switched off for the loads); and when every marching ray
+                    // has at least four such steps the requests skip them -- the next trip's positions are 4 .. 64 rounded
+                    // additions further on (the identity steps of march_packet's runs), with nothing in flight thrown away and
+                    // no latency exposed.
+                    idle_a = DA >= 1u;
+                    idle_b = DB >= 1u;
+                    // steps after pB the ray certainly spends in inert bricks (march_packet's run length; < 0 at an active brick)
+                    const int m = min((int)fminf(((float)DB - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - (i + 1) - 1);
+                    if (__ballot(alive && m < 4) == 0) {
+                        mw = 4;
+                        if (__ballot(alive && m < 8) == 0) {
+                            mw = 8;
+                            if (__ballot(alive && m < 16) == 0) {
+                                mw = 16;
+                                if (__ballot(alive && m < 32) == 0) mw = __ballot(alive && m < 64) == 0 ? 64 : 32;
+                            }
+                        }
+                    }
+                    idle_ra = m >= mw + 1;  // the positions requested now are steps mw + 1 and mw + 2 after pB
+                    idle_rb = m >= mw + 2;
+                }
+#if VR_P2_DEBUG
+                ++dbg_trips;
+                if (mw > 0) ++dbg_jumps;
+#endif
+                tail = i + 2 > n_in_w;
+                one_step(A, afx, afy, afz, pA, pB, i, mw, idle_a, idle_ra, DA);
+                one_step(Bq, bfx, bfy, bfz, pB, pA, i + 1, 0, idle_b, idle_rb, DB);
+                if (mw > 0) {
+                    if constexpr (V == V_LIGHT) {
+                        for (int k = 0; k < mw; ++k) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                    }
+                    if (alive) blends += (unsigned)mw;
+                }
+                i += 2 + mw;
             }
         }
         if (slot.active || (P.packed && slot.in_launch)) P.out[slot.out_index] = dst;
         store_wave_counts(P, lb, blends, covered, fetched, t_start);
+#if VR_P2_DEBUG
+        if ((threadIdx.x & 63) == 0)  // (debug build: the `fetched` word carries the loop's own counters instead)
+            P.block_counts[(size_t)lb * kBlockRecord + 2] = (unsigned long long)(dbg_trips & 0xfffu) | ((unsigned long long)(dbg_sampled & 0xfffu) << 12) |
+                                                           ((unsigned long long)(dbg_shaded & 0xfffu) << 24) | ((unsigned long long)(dbg_jumps & 0xfffu) << 36);
+#endif
         unsigned r = 0;
         if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cls * kPwHeadStride, 1u);
         idx = groups * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
