@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--tf", default="default")
+    ap.add_argument("--air", default="exact0", choices=["exact0", "noisy"])
     ap.add_argument("--flavour", type=int, default=0)
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--world", type=int, default=1, help="trace rank's share of the tiles (tile t -> rank t mod world)")
@@ -26,7 +27,7 @@ def main():
     from volumerendering_amd import capi, host, workloads as wl
     n, W, H, vname = wl.WORKLOADS[a.workload]
     app = host.Application(W, H, 0)
-    variant, vols = wl.build_scene(app, a.workload, a.tf)
+    variant, vols = wl.build_scene(app, a.workload, a.tf, a.air)
     ctx = app.context()
     ctx.set_kernel_flavour(a.flavour)
     for _ in range(6):   # the launch order is three launches old: let it settle
