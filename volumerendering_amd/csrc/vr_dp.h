@@ -174,7 +174,7 @@ __device__ __forceinline__ void march_dp_body(const MarchParams& P, const PixelS
     Fetch4 F4;
     float wfx = 0.0f, wfy = 0.0f, wfz = 0.0f;
     int base = 0;  // step index of depth slot 0 (wave-uniform)
-    while (base < P.steps_count && __ballot(alive) != 0) {
+    while (base < P.steps_count && vr_ballot(alive) != 0) {
         const int my = base + j;
         // next round: K more rounded additions; its distance-field byte is requested now, used at the bottom
         f3 pn = p, wn = w;
@@ -192,13 +192,13 @@ __device__ __forceinline__ void march_dp_body(const MarchParams& P, const PixelS
             // [base, base + mw), all inside the inert neighbourhood of slot 0 and inside the box
             int m = 1 << 30;
             if (alive) m = (D >= 2) ? min((int)fminf(((float)D - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - my - 1) : 0;
-            if (__ballot(m < 4) == 0) {
+            if (vr_ballot(m < 4) == 0) {
                 int mw = 4;
-                if (__ballot(m < 8) == 0) {
+                if (vr_ballot(m < 8) == 0) {
                     mw = 8;
-                    if (__ballot(m < 16) == 0) {
+                    if (vr_ballot(m < 16) == 0) {
                         mw = 16;
-                        if (__ballot(m < 32) == 0) mw = __ballot(m < 64) == 0 ? 64 : 32;
+                        if (vr_ballot(m < 32) == 0) mw = vr_ballot(m < 64) == 0 ? 64 : 32;
                     }
                 }
                 for (int k = 0; k < mw; k += 4) {  // mw is a multiple of 4: one branch per four steps

@@ -99,6 +99,9 @@ __device__ __forceinline__ f3 normalize3s(f3 a)
     float inv = inv_sqrt_exact(dot3s(a, a));
     return mk3(a.x * inv, a.y * inv, a.z * inv);
 }
+// The wavefront's lane mask of a condition.  (HIP's __ballot takes an int: the condition becomes 0 / 1 in a register and is
+// compared again -- v_cndmask + v_cmp and a scalar wait on the vector compare -- where the builtin takes the condition's own mask.)
+__device__ __forceinline__ unsigned long long vr_ballot(bool x) { return __builtin_amdgcn_ballot_w64(x); }
 __device__ __forceinline__ float max0(float x) { return (x > 0.0f) ? x : 0.0f; }
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return mad(b - a, t, a); }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
@@ -251,7 +254,7 @@ __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
     const bool inner = (unsigned)tx < (unsigned)(v.nx - 1) && (unsigned)ty < (unsigned)(v.ny - 1) && (unsigned)tz < (unsigned)(v.nz - 1);
     if (v.bricked) {  // (wave-uniform) bricks of 4 x 4 x 4: the index is a sum of one term per axis (DevVolume)
         int i0 = tx, j0 = ty, k0 = tz, i1 = tx + 1, j1 = ty + 1, k1 = tz + 1;
-        if (__ballot(!inner) != 0) {  // some ray's cell touches a face: the clamp-to-edge texel pairs
+        if (vr_ballot(!inner) != 0) {  // some ray's cell touches a face: the clamp-to-edge texel pairs
             texel_pair(x0, v.nx, i0, i1);
             texel_pair(y0, v.ny, j0, j1);
             texel_pair(z0, v.nz, k0, k1);
@@ -268,7 +271,7 @@ __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
         c.o011 = r11 + ax0; c.o111 = r11 + ax1;
         return c;
     }
-    if (__ballot(!inner) == 0) {
+    if (vr_ballot(!inner) == 0) {
         // every ray of the packet that samples now has its cell strictly inside the volume: nothing to clamp
         c.o000 = ((unsigned)tz * (unsigned)v.ny + (unsigned)ty) * row + (unsigned)tx;
         c.o100 = c.o000 + 1u;
@@ -442,7 +445,7 @@ __device__ __forceinline__ void fetch_rgba_otf(const DevVolume& v, f3 p, Fetch4&
     // the cell and its one-voxel apron strictly inside the grid: 1 <= t <= n - 3 on every axis
     const bool inner = (unsigned)(tx - 1) < (unsigned)(v.nx - 3) && (unsigned)(ty - 1) < (unsigned)(v.ny - 3) &&
                        (unsigned)(tz - 1) < (unsigned)(v.nz - 3) && v.nx >= 4 && v.ny >= 4 && v.nz >= 4;
-    if (__ballot(!inner) == 0) {
+    if (vr_ballot(!inner) == 0) {
         const unsigned row = (unsigned)v.nx, slab = (unsigned)v.nx * (unsigned)v.ny;
         const unsigned b = ((unsigned)tz * (unsigned)v.ny + (unsigned)ty) * row + (unsigned)tx - 1u;  // (x0-1, y0, z0)
         const f4u r00 = load_d4<OFF32>(v.dens, b), r10 = load_d4<OFF32>(v.dens, b + row);
@@ -494,7 +497,7 @@ template <bool UNI = false>
 __device__ __forceinline__ v2f inv_sqrt_exact2(float a, float b)
 {
     bool in_range = (__float_as_uint(a) - 0x21800000u < 0x3c000000u) && (__float_as_uint(b) - 0x21800000u < 0x3c000000u);
-    if constexpr (UNI) in_range = __ballot(!in_range) == 0;
+    if constexpr (UNI) in_range = vr_ballot(!in_range) == 0;
     if (in_range) {
         const v2f x = v2f{a, b};
         v2f y = v2f{__builtin_amdgcn_sqrtf(a), __builtin_amdgcn_sqrtf(b)};
@@ -839,7 +842,7 @@ __device__ __forceinline__ void fetch_mask_and_dose(const MarchParams& P, f3 p, 
     rt = 0.0f;
     any_masked = true;
     if (P.bricks != nullptr && P.use_rgb && P.zskip_prefix >= -1)  // (wave-uniform)
-        any_masked = __ballot(!(brick_record(P, brick_of<OFF32>(P, p)).y <= 0.0f)) != 0;
+        any_masked = vr_ballot(!(brick_record(P, brick_of<OFF32>(P, p)).y <= 0.0f)) != 0;
     if (any_masked) {
         mask = tex3_rgba<OFF32>(P.vol[0], p);
         rt = tex3_a<OFF32>(P.vol[1], p);
@@ -987,7 +990,7 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
 {
     if constexpr (V == V_BASIC && ZSKIP) {
         const float density = tex3_a<OFF32>(P.vol[0], p);
-        if (__ballot(!opacity_is_zero(P, density)) == 0) return;
+        if (vr_ballot(!opacity_is_zero(P, density)) == 0) return;
         const TfSample t = tf_lookup0<LTF>(P, density);
         blend(t.rgb, t.opacity, dst);
     } else if constexpr (V == V_LIGHT) {
@@ -1000,7 +1003,7 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
         else fetch_rgba<OFF32>(P.vol[0], p, q, fx, fy, fz);
         const v2f zw = interp_zw(q, fx, fy, fz);  // (gradient z, density)
         if constexpr (ZSKIP) {
-            if (__ballot(!opacity_is_zero(P, zw.y)) == 0) return;
+            if (vr_ballot(!opacity_is_zero(P, zw.y)) == 0) return;
         }
         const TfFetch tq = tf_fetch0<LTF>(P, zw.y);
         const v2f gxy = interp_xy(q, fx, fy, fz);
@@ -1017,18 +1020,18 @@ __device__ __forceinline__ void sample_and_blend(const MarchParams& P, f3 p, f3 
                 bool any_masked;
                 fetch_mask_and_dose<OFF32>(P, p, mask, rt, any_masked);
                 const bool inert = !(mask.x > 0.0f || mask.y > 0.0f || mask.z > 0.0f) && opacity_is_zero(P, ct.w);
-                if (__ballot(!inert) == 0) return;
+                if (vr_ballot(!inert) == 0) return;
                 const Src s = src_volume_mask<LTF>(P, w, mask, rt, ct, any_masked);
                 blend(s.rgb, s.a, dst);
             } else if constexpr (V == V_THREE_FILES) {
                 const float ct = tex3_a<OFF32>(P.vol[0], p);
                 const float rt = tex3_a<OFF32>(P.vol[1], p);
-                if (__ballot(!opacity_is_zero(P, ct)) == 0) return;
+                if (vr_ballot(!opacity_is_zero(P, ct)) == 0) return;
                 const Src s = src_three_files<LTF>(P, ct, rt);
                 blend(s.rgb, s.a, dst);
             } else {
                 const float density = tex3_a<OFF32>(P.vol[0], p);
-                if (__ballot(!opacity_is_zero(P, density)) == 0) return;
+                if (vr_ballot(!opacity_is_zero(P, density)) == 0) return;
                 const Src s = src_inshader<OFF32, LTF>(P, p, w, ss, density);
                 blend(s.rgb, s.a, dst);
             }
@@ -1419,15 +1422,15 @@ __device__ __forceinline__ void march_packet(const MarchParams& P, const PixelSl
                         // additions back to back (nothing else per step), then look their brick up again.  The rays
                         // of a packet stay at one step index, so their samples keep sharing cache lines.
                         int m = 0;
-                        const bool far = __ballot(D < 2) == 0;  // (one vote decides for a packet that is sampling)
+                        const bool far = vr_ballot(D < 2) == 0;  // (one vote decides for a packet that is sampling)
                         if (far) m = min((int)fminf(((float)D - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - i - 1);
-                        if (far && __ballot(m < 4) == 0) {
+                        if (far && vr_ballot(m < 4) == 0) {
                             int mw = 4;
-                            if (__ballot(m < 8) == 0) {
+                            if (vr_ballot(m < 8) == 0) {
                                 mw = 8;
-                                if (__ballot(m < 16) == 0) {
+                                if (vr_ballot(m < 16) == 0) {
                                     mw = 16;
-                                    if (__ballot(m < 32) == 0) mw = __ballot(m < 64) == 0 ? 64 : 32;
+                                    if (vr_ballot(m < 32) == 0) mw = vr_ballot(m < 64) == 0 ? 64 : 32;
                                 }
                             }
                             for (int k = 0; k < mw; k += 4) {  // mw is a multiple of 4: one branch per four steps
@@ -1459,9 +1462,9 @@ __device__ __forceinline__ void march_packet(const MarchParams& P, const PixelSl
                                 // whose rays still have far to go get the issue slots first (4 levels, by quarters of
                                 // stepsCount; re-evaluated every 8th step; speed only)
                                 const int r = lim - i;
-                                if (__ballot(r > prio_q3) != 0) __builtin_amdgcn_s_setprio(3);
-                                else if (__ballot(r > prio_q2) != 0) __builtin_amdgcn_s_setprio(2);
-                                else if (__ballot(r > prio_q1) != 0) __builtin_amdgcn_s_setprio(1);
+                                if (vr_ballot(r > prio_q3) != 0) __builtin_amdgcn_s_setprio(3);
+                                else if (vr_ballot(r > prio_q2) != 0) __builtin_amdgcn_s_setprio(2);
+                                else if (vr_ballot(r > prio_q1) != 0) __builtin_amdgcn_s_setprio(1);
                                 else __builtin_amdgcn_s_setprio(0);
                             }
                             if constexpr (kPipe) {
@@ -1477,7 +1480,7 @@ __device__ __forceinline__ void march_packet(const MarchParams& P, const PixelSl
                                 if constexpr (V == V_LIGHT) {
                                     if (!have) fetch_rgba<OFF32>(P.vol[0], p, F4, wfx, wfy, wfz);
                                     zw = interp_zw(F4, wfx, wfy, wfz);
-                                    if constexpr (SKIP) all_zero = __ballot(!opacity_is_zero(P, zw.y)) == 0;
+                                    if constexpr (SKIP) all_zero = vr_ballot(!opacity_is_zero(P, zw.y)) == 0;
                                     if (!all_zero) {
                                         tq = tf_fetch0<LTF>(P, zw.y);
                                         gxy = interp_xy(F4, wfx, wfy, wfz);
@@ -1485,7 +1488,7 @@ __device__ __forceinline__ void march_packet(const MarchParams& P, const PixelSl
                                 } else {
                                     if (!have) fetch_a<OFF32>(P.vol[0], p, F1, wfx, wfy, wfz);
                                     zw.y = interp_a(F1, wfx, wfy, wfz);
-                                    if constexpr (SKIP) all_zero = __ballot(!opacity_is_zero(P, zw.y)) == 0;
+                                    if constexpr (SKIP) all_zero = vr_ballot(!opacity_is_zero(P, zw.y)) == 0;
                                     if (!all_zero) tq = tf_fetch0<LTF>(P, zw.y);
                                 }
                                 if constexpr (SKIP) {
@@ -1873,7 +1876,7 @@ __global__ void brick_dist_cap_kernel(unsigned char* __restrict__ dist, int n)
 __global__ void count_active_bricks_kernel(const unsigned char* __restrict__ dist, int n, unsigned* __restrict__ out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long m = __ballot(i < n && dist[i] == 0);
+    const unsigned long long m = vr_ballot(i < n && dist[i] == 0);
     if ((threadIdx.x & 63) == 0 && m != 0) atomicAdd(out, (unsigned)__popcll(m));
 }
 
@@ -1931,7 +1934,7 @@ __global__ void verify_gradient_kernel(const float4* __restrict__ vol, const flo
         bad = __float_as_uint(v.x) != __float_as_uint(grad_cd(px, mx)) || __float_as_uint(v.y) != __float_as_uint(grad_cd(py, my)) ||
               __float_as_uint(v.z) != __float_as_uint(grad_cd(pz, mz)) || v.x != v.x || v.y != v.y || v.z != v.z;
     }
-    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(mismatch, 1u);
+    if (vr_ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(mismatch, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ data preparation

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void march_lt_kernel(const MarchBatch B)
     const bool small_enough = vol.nx <= 65535 && vol.ny <= 65535 && vol.nz <= 65535;
 
     int i = 0;  // step index: the same for every lane
-    while (i < P.steps_count && __ballot(alive) != 0) {
+    while (i < P.steps_count && vr_ballot(alive) != 0) {
         const f3 pn = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
         unsigned Dn = 0;
         if constexpr (SKIP) Dn = dist_at(P, brick_of<OFF32>(P, pn));
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(256) void march_lt_kernel(const MarchBatch B)
             // wave-uniform run of identity steps (march_kernel): every ray that is still marching has at least 4 safe steps
             int m = 1 << 30;
             if (alive) m = (D >= 2) ? min((int)fminf(((float)D - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - i - 1) : 0;
-            if (__ballot(m < 4) == 0) {
+            if (vr_ballot(m < 4) == 0) {
                 int mw = 4;
-                if (__ballot(m < 8) == 0) {
+                if (vr_ballot(m < 8) == 0) {
                     mw = 8;
-                    if (__ballot(m < 16) == 0) {
+                    if (vr_ballot(m < 16) == 0) {
                         mw = 16;
-                        if (__ballot(m < 32) == 0) mw = __ballot(m < 64) == 0 ? 64 : 32;
+                        if (vr_ballot(m < 32) == 0) mw = vr_ballot(m < 64) == 0 ? 64 : 32;
                     }
                 }
                 for (int k = 0; k < mw; k += 4) {
@@ -163,12 +163,12 @@ __global__ __launch_bounds__(256) void march_lt_kernel(const MarchBatch B)
                     (step.y <= 0.0f && p.y < by0) || (step.z >= 0.0f && p.z > bz1) || (step.z <= 0.0f && p.z < bz0));
         }
         const bool real = inb && (!SKIP || D == 0);
-        if (__ballot(real) != 0) {  // (wave-uniform: every lane of the wavefront is here)
+        if (vr_ballot(real) != 0) {  // (wave-uniform: every lane of the wavefront is here)
             const LtCell c = lt_cell(vol, p);
             bool use_tile = false;
             if (small_enough) {
                 const bool inside = !real || (tile_ok && c.i0 >= tx0 && c.i1 <= tx1 && c.j0 >= ty0 && c.j1 <= ty1 && c.k0 >= tz0 && c.k1 <= tz1);
-                const bool all_inside = __ballot(!inside) == 0;
+                const bool all_inside = vr_ballot(!inside) == 0;
                 // a tile is built at most once per kLtSteps steps: a ray that starts sampling outside the current tile (the
                 // packet straddles the body's silhouette) sends THIS step through the direct gather instead of forcing a new
                 // tile on everybody, and a box that did not fit is not tried again before kLtSteps steps have passed
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void march_lt_kernel(const MarchBatch B)
                 }
                 const v2f zw = interp_zw(q, c.fx, c.fy, c.fz);
                 bool all_zero = false;
-                if constexpr (SKIP) all_zero = __ballot(!opacity_is_zero(P, zw.y)) == 0;
+                if constexpr (SKIP) all_zero = vr_ballot(!opacity_is_zero(P, zw.y)) == 0;
                 if (!all_zero) {
                     const TfFetch tq = tf_fetch(P.tf[0], zw.y);
                     const v2f gxy = interp_xy(q, c.fx, c.fy, c.fz);

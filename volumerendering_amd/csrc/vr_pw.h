@@ -149,7 +149,7 @@ __device__ __forceinline__ void p2_request(const DevVolume& vol, __amdgpu_buffer
     unsigned long long exec_saved = 0;
     if constexpr (MASKED) {
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]));
-        const unsigned long long keep = __ballot(!idle);
+        const unsigned long long keep = vr_ballot(!idle);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1" : "=&s"(exec_saved) : "s"(keep) : "scc");
     }
@@ -201,8 +201,19 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
     const float bx0 = P.bmin[0], by0 = P.bmin[1], bz0 = P.bmin[2];
     const float bx1 = P.bmax[0], by1 = P.bmax[1], bz1 = P.bmax[2];
     typedef typename std::conditional<V == V_LIGHT, vr_f4, float>::type Elem;
-    while (idx < n_c) {
-        const unsigned pos = (idx << 3) | cls;
+    unsigned cur = cls, tried = 0;  // (stealing between classes: march_pw_kernel's)
+    for (;;) {
+        if (idx >= n_c) {
+            if (!Q.steal || ++tried >= 8u) break;
+            cur = (cur + 1u) & 7u;
+            const unsigned groups_o = (gridDim.x - cur + 7u) >> 3;
+            unsigned r = 0;
+            if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
+            idx = groups_o * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+            continue;
+        }
+        tried = 0;
+        const unsigned pos = (idx << 3) | cur;
         int lb = (int)pos;
         if (P.order != nullptr) lb = __builtin_amdgcn_readfirstlane((int)P.order[pos]);
         const unsigned long long t_start = wall_clock64();
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 }
             }
         }
-        if (__ballot(alive) != 0) {  // (wave-uniform: from here on every lane executes every statement)
+        if (vr_ballot(alive) != 0) {  // (wave-uniform: from here on every lane executes every statement)
             // A wavefront issues its instructions in order, one at a time: about 5 cycles a vector instruction, 8 a scalar one, 29
             // a compare whose mask a scalar instruction combines (tools/ubench/valu_issue.hip, 3 wavefronts per SIMD) -- with the
             // loads two steps ahead the loop's own instruction stream is the step's latency, and mask logic is its dearest part.
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 v2f zw = v2f{0.0f, 0.0f}, gxy;
                 TfFetch tq;
                 // (wave-uniform) a step in which no ray samples interpolates nothing
-                bool shaded = !SKIP || __ballot(sampled) != 0;
+                bool shaded = !SKIP || vr_ballot(sampled) != 0;
 #if VR_P2_DEBUG
                 if (shaded) ++dbg_sampled;
 #endif
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     zw = interp_zw(q, xfx, xfy, xfz);
                     // (the per-step vote of sample_and_blend: when every ray's opacity is zero for certain, the texels, the
                     // gradient and the shading are left out -- the blend would be the identity)
-                    if constexpr (SKIP) shaded = __ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
+                    if constexpr (SKIP) shaded = vr_ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
                     if (shaded) {
                         tq = tf_fetch_lds(P.tf[0], zw.y);
                         gxy = interp_xy(q, xfx, xfy, xfz);
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     Fetch1 q;
                     q.a = X[0]; q.b = X[1]; q.d = X[2]; q.e = X[3]; q.f = X[4]; q.g = X[5]; q.h = X[6]; q.i = X[7];
                     zw.y = interp_a(q, xfx, xfy, xfz);
-                    if constexpr (SKIP) shaded = __ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
+                    if constexpr (SKIP) shaded = vr_ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
                     if (shaded) tq = tf_fetch_lds(P.tf[0], zw.y);
                 }
                 // the position of the next request into X.  (Only now: the box test above read pX.)
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
 #if VR_P2_DEBUG
             dbg_trips = dbg_sampled = dbg_shaded = dbg_jumps = 0;
 #endif
-            while (i < P.steps_count && __ballot(alive) != 0) {
+            while (i < P.steps_count && vr_ballot(alive) != 0) {
                 if (start) {
                     // the bytes of pA and pB and, without waiting for them, the corners of steps 0 and 1 of every ray
                     pB = mk3(pA.x + step.x, pA.y + step.y, pA.z + step.z);
@@ -408,13 +419,13 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     idle_b = DB >= 1u;
                     // steps after pB the ray certainly spends in inert bricks (march_packet's run length; < 0 at an active brick)
                     const int m = min((int)fminf(((float)DB - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - (i + 1) - 1);
-                    if (__ballot(alive && m < 4) == 0) {
+                    if (vr_ballot(alive && m < 4) == 0) {
                         mw = 4;
-                        if (__ballot(alive && m < 8) == 0) {
+                        if (vr_ballot(alive && m < 8) == 0) {
                             mw = 8;
-                            if (__ballot(alive && m < 16) == 0) {
+                            if (vr_ballot(alive && m < 16) == 0) {
                                 mw = 16;
-                                if (__ballot(alive && m < 32) == 0) mw = __ballot(alive && m < 64) == 0 ? 64 : 32;
+                                if (vr_ballot(alive && m < 32) == 0) mw = vr_ballot(alive && m < 64) == 0 ? 64 : 32;
                             }
                         }
                     }
@@ -445,8 +456,9 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                                                            ((unsigned long long)(dbg_shaded & 0xfffu) << 24) | ((unsigned long long)(dbg_jumps & 0xfffu) << 36);
 #endif
         unsigned r = 0;
-        if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cls * kPwHeadStride, 1u);
-        idx = groups * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+        if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
+        const unsigned groups_cur = (gridDim.x - cur + 7u) >> 3;
+        idx = groups_cur * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
     }
 }
 
