@@ -264,8 +264,10 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             // A wavefront issues its instructions in order, one at a time: about 5 cycles a vector instruction, 8 a scalar one, 29
             // a compare whose mask a scalar instruction combines (tools/ubench/valu_issue.hip, 3 wavefronts per SIMD) -- with the
             // loads two steps ahead the loop's own instruction stream is the step's latency, and mask logic is its dearest part.
-            // Hence: no per-step bookkeeping that a trip (two steps) can do once, the box test only for the last steps of a packet
-            // (tail: behind a scalar branch), wave-uniform choices wherever the result is the same.
+            // Hence: no per-step bookkeeping that a trip (two steps) can do once, wave-uniform choices wherever the result is the
+            // same, and no box test at all in this loop: it runs while every marching ray is provably inside the box and in time
+            // (a wave-minimum of the rays' own counts says how long); the last steps of a packet -- rays leave the box a few
+            // steps apart -- are taken by a plain loop behind it.
             //
             // Two corner buffers: A = even steps, Bq = odd steps of a trip, the loop unrolled by two so that which registers hold
             // which step is static; a buffer is written by requests inside the loop only (no prologue that loads them: the
@@ -308,16 +310,11 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             }
             bool idle_a = false, idle_b = false;      // this trip: step A / B blends nothing
             bool idle_ra = false, idle_rb = false;    // ... requests nothing
-            bool tail = false;                        // this trip's steps need the box test (wave-uniform)
             int mw = 0;                               // identity steps skipped between this trip's two steps and the next trip's
             // consumes the corners in X (of position pX, step ix), then requests into X the corners of pY + step [+ mw steps], which
             // becomes pX
             auto one_step = [&](Elem (&X)[8], float& xfx, float& xfy, float& xfz, f3& pX, const f3& pY, int ix, int jump, bool idle_con, bool idle_rq, unsigned& DX) {
-                bool inb = alive, in_time = alive;
-                if (tail) {
-                    in_time = alive && ix < P.steps_count;
-                    inb = in_time && (ix < n_inside || (pX.x >= bx0 && pX.x <= bx1 && pX.y >= by0 && pX.y <= by1 && pX.z >= bz0 && pX.z <= bz1));
-                }
+                const bool inb = alive;  // (in time and inside the box: the loop's condition)
                 const bool sampled = SKIP ? (inb && !idle_con) : inb;
                 v2f zw = v2f{0.0f, 0.0f}, gxy;
                 TfFetch tq;
@@ -348,8 +345,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     if constexpr (SKIP) shaded = vr_ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
                     if (shaded) tq = tf_fetch_lds(P.tf[0], zw.y);
                 }
-                // the position of the next request into X.  (Only now: the box test above read pX.)
-                const f3 gone_p = pX;  // (the position this step was at: the tail's test below)
+                // the position of the next request into X
                 pX = mk3(pY.x + step.x, pY.y + step.y, pY.z + step.z);
                 for (int k = 0; k < jump; ++k) pX = mk3(pX.x + step.x, pX.y + step.y, pX.z + step.z);
                 // Everything that reads the old corners must be COMPUTED here, before their registers are loaded again: left alone,
@@ -380,21 +376,13 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 if (inb) ++blends;
                 // cut-off reached: no later step can blend (dst.w changes in a sampled step only: the test is the loop's own)
                 alive = alive && can_blend<V>(dst.w);
-                if (tail) {
-                    if (in_time && !inb) {
-                        // a position moves monotonically per component: once past the far bound it never returns
-                        const bool gone = (step.x >= 0.0f && gone_p.x > bx1) || (step.x <= 0.0f && gone_p.x < bx0) || (step.y >= 0.0f && gone_p.y > by1) ||
-                                          (step.y <= 0.0f && gone_p.y < by0) || (step.z >= 0.0f && gone_p.z > bz1) || (step.z <= 0.0f && gone_p.z < bz0);
-                        if (gone) alive = false;
-                    }
-                }
                 if constexpr (V == V_LIGHT) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
             };
             bool start = true;  // (wave-uniform) nothing is in flight yet
 #if VR_P2_DEBUG
             dbg_trips = dbg_sampled = dbg_shaded = dbg_jumps = 0;
 #endif
-            while (i < P.steps_count && vr_ballot(alive) != 0) {
+            while (i + 2 <= n_in_w && vr_ballot(alive) != 0) {
                 if (start) {
                     // the bytes of pA and pB and, without waiting for them, the corners of steps 0 and 1 of every ray
                     pB = mk3(pA.x + step.x, pA.y + step.y, pA.z + step.z);
@@ -436,7 +424,6 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 ++dbg_trips;
                 if (mw > 0) ++dbg_jumps;
 #endif
-                tail = i + 2 > n_in_w;
                 one_step(A, afx, afy, afz, pA, pB, i, mw, idle_a, idle_ra, DA);
                 one_step(Bq, bfx, bfy, bfz, pB, pA, i + 1, 0, idle_b, idle_rb, DB);
                 if (mw > 0) {
@@ -446,6 +433,32 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     if (alive) blends += (unsigned)mw;
                 }
                 i += 2 + mw;
+            }
+            // The last steps of the packet (pA is the exact position of step i, w its world position): the shader's loop as it
+            // stands -- box test, identity steps by the distance-field byte, the far-bound exit -- with no loads ahead.
+            if (!start) p = pA;
+            for (; i < P.steps_count && vr_ballot(alive) != 0; ++i) {
+                if (alive) {
+                    bool inb = true;
+                    if (i >= n_inside) inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
+                    if (inb) {
+                        bool sampled = true;
+                        if constexpr (SKIP) sampled = dist_at(P, brick_of<true>(P, p)) == 0u;
+                        if (sampled) {
+                            sample_and_blend<V, true, false, SKIP, true>(P, p, w, dst, mk3(0.0f, 0.0f, 0.0f), 0.0f);
+                            ++fetched;
+                        }
+                        ++blends;
+                        if (!can_blend<V>(dst.w)) alive = false;  // cut-off reached: no later step can blend
+                    } else {
+                        // p moves monotonically per component: once past the far bound it never returns
+                        const bool gone = (step.x >= 0.0f && p.x > bx1) || (step.x <= 0.0f && p.x < bx0) || (step.y >= 0.0f && p.y > by1) ||
+                                          (step.y <= 0.0f && p.y < by0) || (step.z >= 0.0f && p.z > bz1) || (step.z <= 0.0f && p.z < bz0);
+                        if (gone) alive = false;
+                    }
+                }
+                p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                if constexpr (V == V_LIGHT) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
             }
         }
         if (slot.active || (P.packed && slot.in_launch)) P.out[slot.out_index] = dst;
