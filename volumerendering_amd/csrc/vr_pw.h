@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 v2f zw = v2f{0.0f, 0.0f}, gxy;
                 TfFetch tq;
                 // (wave-uniform) a step in which no ray samples interpolates nothing
-                bool shaded = !SKIP || vr_ballot(sampled) != 0;
+                bool shaded = !SKIP || vr_ballot(!idle_con) != 0;  // (idle_con covers the rays that had finished when the trip began)
 #if VR_P2_DEBUG
                 if (shaded) ++dbg_sampled;
 #endif
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     zw = interp_zw(q, xfx, xfy, xfz);
                     // (the per-step vote of sample_and_blend: when every ray's opacity is zero for certain, the texels, the
                     // gradient and the shading are left out -- the blend would be the identity)
-                    if constexpr (SKIP) shaded = vr_ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
+                    if constexpr (SKIP) shaded = vr_ballot(sampled & !opacity_is_zero(P, zw.y)) != 0;  // (&: no branch round the test)
                     if (shaded) {
                         tq = tf_fetch_lds(P.tf[0], zw.y);
                         gxy = interp_xy(q, xfx, xfy, xfz);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     Fetch1 q;
                     q.a = X[0]; q.b = X[1]; q.d = X[2]; q.e = X[3]; q.f = X[4]; q.g = X[5]; q.h = X[6]; q.i = X[7];
                     zw.y = interp_a(q, xfx, xfy, xfz);
-                    if constexpr (SKIP) shaded = vr_ballot(sampled && !opacity_is_zero(P, zw.y)) != 0;
+                    if constexpr (SKIP) shaded = vr_ballot(sampled & !opacity_is_zero(P, zw.y)) != 0;  // (&: no branch round the test)
                     if (shaded) tq = tf_fetch_lds(P.tf[0], zw.y);
                 }
                 // the position of the next request into X
@@ -403,17 +403,21 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     // has at least four such steps the requests skip them -- the next trip's positions are 4 .. 64 rounded
                     // additions further on (the identity steps of march_packet's runs), with nothing in flight thrown away and
                     // no latency exposed.
-                    idle_a = DA >= 1u;
-                    idle_b = DB >= 1u;
+                    // (A finished ray is folded into the VALUES -- byte 255, any number of safe steps -- so that every vote below is
+                    // the lane mask of ONE compare: a vote on `alive && x < k` costs a mask AND, a v_cndmask and a second compare.)
+                    const unsigned da = alive ? DA : 255u, db = alive ? DB : 255u;
+                    idle_a = da >= 1u;
+                    idle_b = db >= 1u;
                     // steps after pB the ray certainly spends in inert bricks (march_packet's run length; < 0 at an active brick)
-                    const int m = min((int)fminf(((float)DB - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - (i + 1) - 1);
-                    if (vr_ballot(alive && m < 4) == 0) {
+                    int m = min((int)fminf(((float)db - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - (i + 1) - 1);
+                    m = alive ? m : 64;
+                    if (vr_ballot(m < 4) == 0) {
                         mw = 4;
-                        if (vr_ballot(alive && m < 8) == 0) {
+                        if (vr_ballot(m < 8) == 0) {
                             mw = 8;
-                            if (vr_ballot(alive && m < 16) == 0) {
+                            if (vr_ballot(m < 16) == 0) {
                                 mw = 16;
-                                if (vr_ballot(alive && m < 32) == 0) mw = vr_ballot(alive && m < 64) == 0 ? 64 : 32;
+                                if (vr_ballot(m < 32) == 0) mw = vr_ballot(m < 64) == 0 ? 64 : 32;
                             }
                         }
                     }
