@@ -165,6 +165,17 @@ __device__ __forceinline__ void p2_request(const DevVolume& vol, __amdgpu_buffer
     }
 }
 
+// The per-step vote of sample_and_blend (opacity_is_zero for every sampling ray) as ONE compare: the table index that decides,
+// with "not finite" and "does not sample" folded into its value.
+__device__ __forceinline__ bool p2_vote(const MarchParams& P, bool sampled, float d)
+{
+    int j = padded_texel(floorf(mad(d, (float)P.tf[0].res_o, -0.5f)), P.tf[0].res_o);
+    j = (d - d == 0.0f) ? j : 0x7fffffff;          // an infinite density has a NaN weight, hence a NaN opacity: never "zero"
+    j = sampled ? j : (int)0x80000000;             // a ray that does not sample never asks for the shading
+    asm volatile("" : "+v"(j));                    // (kept as a value: the compiler would turn the compare back into mask logic)
+    return vr_ballot(j > P.zskip_prefix) != 0;
+}
+
 // SKIP: empty-space skipping on top of it.  One distance-field byte per ray rides along with each corner buffer: the byte of
 // the exact position whose corners are in flight, asked for just ahead of them and read a trip later.  It says whether the
 // step blends (an inert brick: the identity, march_packet's test), whether the two steps after it need their corners at all
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     zw = interp_zw(q, xfx, xfy, xfz);
                     // (the per-step vote of sample_and_blend: when every ray's opacity is zero for certain, the texels, the
                     // gradient and the shading are left out -- the blend would be the identity)
-                    if constexpr (SKIP) shaded = vr_ballot(sampled & !opacity_is_zero(P, zw.y)) != 0;  // (&: no branch round the test)
+                    if constexpr (SKIP) shaded = p2_vote(P, sampled, zw.y);
                     if (shaded) {
                         tq = tf_fetch_lds(P.tf[0], zw.y);
                         gxy = interp_xy(q, xfx, xfy, xfz);
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     Fetch1 q;
                     q.a = X[0]; q.b = X[1]; q.d = X[2]; q.e = X[3]; q.f = X[4]; q.g = X[5]; q.h = X[6]; q.i = X[7];
                     zw.y = interp_a(q, xfx, xfy, xfz);
-                    if constexpr (SKIP) shaded = vr_ballot(sampled & !opacity_is_zero(P, zw.y)) != 0;  // (&: no branch round the test)
+                    if constexpr (SKIP) shaded = p2_vote(P, sampled, zw.y);
                     if (shaded) tq = tf_fetch_lds(P.tf[0], zw.y);
                 }
                 // the position of the next request into X
@@ -405,7 +416,8 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     // no latency exposed.
                     // (A finished ray is folded into the VALUES -- byte 255, any number of safe steps -- so that every vote below is
                     // the lane mask of ONE compare: a vote on `alive && x < k` costs a mask AND, a v_cndmask and a second compare.)
-                    const unsigned da = alive ? DA : 255u, db = alive ? DB : 255u;
+                    unsigned da = alive ? DA : 255u, db = alive ? DB : 255u;
+                    asm volatile("" : "+v"(da), "+v"(db));  // (kept as values: the compiler would turn `da >= 1` back into mask logic)
                     idle_a = da >= 1u;
                     idle_b = db >= 1u;
                     // steps after pB the ray certainly spends in inert bricks (march_packet's run length; < 0 at an active brick)
