@@ -131,13 +131,19 @@ __device__ __forceinline__ Cell make_cell_bricked(const DevVolume& v, f3 p)
 }
 
 // requests the eight corners of position q into X, returns the interpolation weights.  MASKED: the lanes that say `idle`
-// request nothing.
+// request nothing; and the distance-field byte of q's brick is asked for just ahead of the corners (every lane) -- the
+// skipping's bricks ARE the layout's bricks (brick_of(q) is the base cell's brick: see its comment), so the byte's index is the
+// base corner's slot without its six intra-brick bits, for one shift instead of brick_of's twelve instructions.
 template <int V, bool MASKED = false, typename T>
-__device__ __forceinline__ void p2_request(const DevVolume& vol, __amdgpu_buffer_rsrc_t rsrc, f3 q, T (&X)[8], float& fx, float& fy, float& fz,
-                                           bool idle = false)
+__device__ __forceinline__ void p2_request(const MarchParams& P, const DevVolume& vol, __amdgpu_buffer_rsrc_t rsrc, f3 q, T (&X)[8], float& fx,
+                                           float& fy, float& fz, bool idle, unsigned& dbyte)
 {
     constexpr unsigned kShift = (V == V_LIGHT) ? 4u : 2u;  // bytes per element
     const Cell c = make_cell_bricked(vol, q);
+    if constexpr (MASKED) {
+        if constexpr (kBrickShift == (int)kVbS) dbyte = dist_at(P, (int)(c.o000 >> (3u * kVbS)));
+        else dbyte = dist_at(P, brick_of<true>(P, q));
+    }
     fx = c.fx;
     fy = c.fy;
     fz = c.fz;
@@ -366,9 +372,8 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 if constexpr (V == V_LIGHT) asm volatile("" : "+v"(zw.x), "+v"(zw.y), "+v"(gxy.x), "+v"(gxy.y));
                 else asm volatile("" : "+v"(zw.y));
                 __builtin_amdgcn_sched_barrier(0);  // the old corners are dead here: the new ones may land in their registers
-                // the byte of the position requested: the next trip decides with it (asked for ahead of the corner loads)
-                if constexpr (SKIP) DX = dist_at(P, brick_of<true>(P, pX));
-                p2_request<V, SKIP>(vol, rsrc, pX, X, xfx, xfy, xfz, SKIP && (idle_rq || !alive));
+                // (with the byte of the position requested: the next trip decides with it)
+                p2_request<V, SKIP>(P, vol, rsrc, pX, X, xfx, xfy, xfz, SKIP && (idle_rq || !alive), DX);
                 __builtin_amdgcn_sched_barrier(0);
 #if VR_P2_DEBUG
                 if (shaded) ++dbg_shaded;
@@ -397,12 +402,8 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 if (start) {
                     // the bytes of pA and pB and, without waiting for them, the corners of steps 0 and 1 of every ray
                     pB = mk3(pA.x + step.x, pA.y + step.y, pA.z + step.z);
-                    if constexpr (SKIP) {
-                        DA = dist_at(P, brick_of<true>(P, pA));
-                        DB = dist_at(P, brick_of<true>(P, pB));
-                    }
-                    p2_request<V, SKIP>(vol, rsrc, pA, A, afx, afy, afz, SKIP && !alive);
-                    p2_request<V, SKIP>(vol, rsrc, pB, Bq, bfx, bfy, bfz, SKIP && !alive);
+                    p2_request<V, SKIP>(P, vol, rsrc, pA, A, afx, afy, afz, SKIP && !alive, DA);
+                    p2_request<V, SKIP>(P, vol, rsrc, pB, Bq, bfx, bfy, bfz, SKIP && !alive, DB);
                     start = false;
                 }
                 mw = 0;
