@@ -1012,6 +1012,50 @@ def test_persistent_wavefronts_block_records(ctx):
         ctx.resize(96, 80)
 
 
+# ---- two steps ahead (flavours 16 / 17, csrc/vr_pw.h: march_p2_kernel) ------------------------------------------------------------
+@pytest.mark.parametrize("variant", [capi.LIGHT, capi.BASIC])
+def test_two_steps_ahead_jumps_idle_rays_and_the_last_steps(ctx, variant):
+    """The two-steps-ahead kernels where their own machinery is exercised most: a small dense body in a large empty volume (jumps
+    of every length, rays that are idle beside rays that sample, trips in which nothing blends), seen from far, near and from
+    inside, through clip boxes that end the rays inside the body (the plain loop behind the pipelined one takes the last steps:
+    rays of a packet leave the box at different steps), with jitter and the variable step, few steps (the pipelined loop is
+    never entered) and many, a table with and without a zero prefix.  Frames bit-equal to the oracle; composited, covered and
+    fetched counts per packet equal to march_kernel's for 17 (16 fetches every composited sample)."""
+    n = 48
+    rng = np.random.default_rng(11)
+    raw = np.zeros((n, n, n), dtype=np.uint16)
+    zz, yy, xx = np.mgrid[0:n, 0:n, 0:n]
+    body = (xx - 30) ** 2 + (yy - 20) ** 2 + (zz - 26) ** 2 < 7 ** 2
+    raw[body] = (1500 + rng.integers(0, 1500, size=int(body.sum()))).astype(np.uint16)
+    raw[10:13, 30:44, 8:40] = 2600                                   # a thin plate: rays graze it
+    vol = ob.precompute_gradient(ob.normalize_data(hr.raw_to_vec4(raw)))
+    W, H = 200, 120
+    step, count = hr.stepping_params(n, n, n)
+    cases = [dict(), dict(yaw=1.0, pitch=-0.4, distance=1.6), dict(yaw=-2.3, pitch=0.7, distance=0.6),
+             dict(clip_x=(0.5, 0.1), clip_z=(0.0, 0.45)), dict(clip_y=(0.3, 0.35), yaw=0.4),
+             dict(toggles=(1, 1, 0, 0), yaw=2.0), dict(steps_count=3), dict(steps_count=1), dict(step_size=step / 3, steps_count=3 * count)]
+    try:
+        for zeros in (9, 0):
+            tf = zero_prefix_tf(64, zeros, top=0.6)
+            for kw in cases:
+                args = dict(steps_count=count, step_size=step)
+                args.update(kw)
+                u = hr.make_uniforms(W, H, **args)
+                recs = {}
+                for fl in (6, 17, 16):
+                    ctx.set_kernel_flavour(fl)
+                    check(ctx, variant, u, [vol], [tf], W, H)
+                    assert ctx.last_kernel_flavour() == fl
+                    recs[fl] = ctx.block_trace().astype(np.uint64)
+                a, b, c = recs[6], recs[17], recs[16]
+                assert a.shape == b.shape == c.shape and a.shape[0] > 0
+                assert np.array_equal(a[:, :3], b[:, :3]), kw          # composited, covered, fetched per packet
+                assert np.array_equal(a[:, :2], c[:, :2]) and np.array_equal(c[:, 2], c[:, 0]), kw
+    finally:
+        ctx.set_kernel_flavour(0)
+        ctx.resize(96, 80)
+
+
 # ---- lanes per ray chosen per packet (flavour 14, csrc/vr_mixed.h) -----------------------------------------------------------
 @pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.VOLUME_MASK, capi.THREE_FILES, capi.MULTI_CTRT, capi.TF_CALIB])
 def test_mixed_lanes_per_ray_per_packet(ctx, variant, monkeypatch):

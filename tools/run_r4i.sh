@@ -1,7 +1,7 @@
 #!/bin/bash
 # a rank's share of the tiles (rehearsal on one GPU): the default against flavour 17 and 12
 set -x
-O=gpurun_out/r4i
+O=gpurun_out/r4t
 mkdir -p $O
 for N in 2 4 8; do
  for fl in 0 17; do
@@ -10,7 +10,7 @@ for N in 2 4 8; do
 done
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/r4i/*.json')):
+for f in sorted(glob.glob('gpurun_out/r4t/*.json')):
     d=json.load(open(f))
     print(f.split('/')[-1], 'serial', d['serial']['ms_per_step'], d['serial'].get('kernel_ms_median'), 'fl', d['config'].get('kernel_flavour_resolved'), 'ovl', d['overlapped']['ms_per_step'], d.get('rank0_stage_timeline'))
 PY

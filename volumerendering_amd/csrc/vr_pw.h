@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             int mw = 0;                               // identity steps skipped between this trip's two steps and the next trip's
             // consumes the corners in X (of position pX, step ix), then requests into X the corners of pY + step [+ mw steps], which
             // becomes pX
-            auto one_step = [&](Elem (&X)[8], float& xfx, float& xfy, float& xfz, f3& pX, const f3& pY, int ix, int jump, bool idle_con, bool idle_rq, unsigned& DX) {
+            auto one_step = [&](Elem (&X)[8], float& xfx, float& xfy, float& xfz, f3& pX, const f3& pY, int jump, bool idle_con, bool idle_rq, unsigned& DX) {
                 const bool inb = alive;  // (in time and inside the box: the loop's condition)
                 const bool sampled = SKIP ? (inb && !idle_con) : inb;
                 v2f zw = v2f{0.0f, 0.0f}, gxy;
@@ -441,8 +441,8 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 ++dbg_trips;
                 if (mw > 0) ++dbg_jumps;
 #endif
-                one_step(A, afx, afy, afz, pA, pB, i, mw, idle_a, idle_ra, DA);
-                one_step(Bq, bfx, bfy, bfz, pB, pA, i + 1, 0, idle_b, idle_rb, DB);
+                one_step(A, afx, afy, afz, pA, pB, mw, idle_a, idle_ra, DA);
+                one_step(Bq, bfx, bfy, bfz, pB, pA, 0, idle_b, idle_rb, DB);
                 if (mw > 0) {
                     if constexpr (V == V_LIGHT) {
                         for (int k = 0; k < mw; ++k) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
