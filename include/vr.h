@@ -324,13 +324,14 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *      each corner buffer; idle rays' lanes are switched off for the loads; runs of identity steps become jumps of the requests
  *      while the steps in flight are consumed; 3 wavefronts per SIMD); else it runs as 12.  The default for whole frames of
  *      the lit / unlit shader whose longest ray chain is 200 .. 400 samples
- *   14  lanes per ray chosen PER PACKET (csrc/vr_mixed.h): packets whose longest ray chain in an earlier launch of the same
- *      shape reached 75 % of that launch's longest are marched as two half packets with two lanes per ray, the rest with
- *      one; one-frame launches of the shaders that have a depth-parallel form                                  */
+ *   14  (experimental build) lanes per ray chosen PER PACKET (csrc/vr_mixed.h): packets whose longest ray chain in an earlier
+ *      launch of the same shape reached 75 % of that launch's longest are marched as two half packets with two lanes per ray,
+ *      the rest with one; one-frame launches of the shaders that have a depth-parallel form
+ *   15  (experimental build) LDS tiles filled by LDS-DMA (csrc/vr_lt.h): lit shader, launches of one frame          */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 
-/* 1 if the library was built with -DVR_EXPERIMENTAL_FLAVOURS=1: the kernel forms that lost every A/B -- flavours 2, 3, 4, 5, 9
- * and volume layout 2 -- are then compiled in; 0 (the shipped build): vr_set_kernel_flavour / vr_set_volume_layout return
+/* 1 if the library was built with -DVR_EXPERIMENTAL_FLAVOURS=1: the kernel forms that lost every A/B -- flavours 2, 3, 4, 5, 9,
+ * 14, 15 and volume layout 2 -- are then compiled in; 0 (the shipped build): vr_set_kernel_flavour / vr_set_volume_layout return
  * VR_ERR_UNSUPPORTED for them.                                                                                           */
 int vr_experimental_flavours(void);
 

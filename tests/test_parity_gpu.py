@@ -248,7 +248,7 @@ def test_skipping_with_hostile_values(ctx):
         for variant in (capi.BASIC, capi.LIGHT):
             ref, n_ref, _ = ob.render(variant, u, [lone], [tf], W, H, nthreads=8)
             assert np.isnan(ref).any()
-            for flavour in (0, 6, 11, 12, 13, 15):
+            for flavour in vt.flavours(0, 6, 11, 12, 13, 15, 16, 17):
                 ctx.set_kernel_flavour(flavour)
                 frag, _, ns = vt.gpu_render(ctx, variant, u, [lone], [tf])
                 assert same(frag, ref) and ns == n_ref, (bad, where, variant, flavour)
@@ -434,7 +434,7 @@ def test_default_layout_follows_launch_size(ctx):
     ctx.resize(W, H)
     try:
         frames = []
-        for fl in (0, 6, 7, 8, 10, 11, 12, 13, 15):
+        for fl in vt.flavours(0, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17):
             ctx.set_kernel_flavour(fl)
             frag, _, n = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
             frames.append((vt.bits(frag), n))
@@ -1057,6 +1057,7 @@ def test_two_steps_ahead_jumps_idle_rays_and_the_last_steps(ctx, variant):
 
 
 # ---- lanes per ray chosen per packet (flavour 14, csrc/vr_mixed.h) -----------------------------------------------------------
+@pytest.mark.skipif(not vt.experimental(), reason="flavour 14 needs VR_EXPERIMENTAL_FLAVOURS=1")
 @pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.VOLUME_MASK, capi.THREE_FILES, capi.MULTI_CTRT, capi.TF_CALIB])
 def test_mixed_lanes_per_ray_per_packet(ctx, variant, monkeypatch):
     """Flavour 14: from the fourth launch or so the packets with the longest chains are marched as two half packets with two
@@ -1094,6 +1095,7 @@ def test_mixed_lanes_per_ray_per_packet(ctx, variant, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.skipif(not vt.experimental(), reason="flavour 14 needs VR_EXPERIMENTAL_FLAVOURS=1")
 def test_mixed_lanes_per_ray_at_1080p_and_every_threshold(ctx, monkeypatch):
     """A 1080p frame (32 640 packets), packed tiles of a two-rank partition, and thresholds from 'split everything that samples'
     to 'split nothing': always the one-lane kernel's frame and counts."""
@@ -1121,6 +1123,7 @@ def test_mixed_lanes_per_ray_at_1080p_and_every_threshold(ctx, monkeypatch):
 
 
 # ---- LDS tiles filled by LDS-DMA (flavour 15, csrc/vr_lt.h) ------------------------------------------------------------------
+@pytest.mark.skipif(not vt.experimental(), reason="flavour 15 needs VR_EXPERIMENTAL_FLAVOURS=1")
 def test_lds_tiles_by_lds_dma(ctx):
     """Flavour 15: the voxels of the next four steps of a packet are fetched once into the wavefront's LDS tile by
     global_load_lds_dwordx4 and the corner gathers read LDS.  Volumes whose boxes fit and volumes whose boxes do not (a 200^3

@@ -45,8 +45,8 @@ def test_random_combinations_bit_exact(seed):
             fused = bool(rng.integers(0, 2))
             flavour = int(rng.choice([0, 0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17]))
             layout = int(rng.choice([0, 0, 1, 2, 3]))
-            if not vt.experimental():  # (the shipped build has no flavours 4 / 5 / 9 and no layout 2: csrc/vr_launch.h)
-                flavour = {4: 12, 5: 13, 9: 15}.get(flavour, flavour)
+            if not vt.experimental():  # (the shipped build has no flavours 4 / 5 / 9 / 14 / 15 and no layout 2: csrc/vr_launch.h)
+                flavour = {4: 12, 5: 13, 9: 16, 14: 17, 15: 11}.get(flavour, flavour)
                 layout = 3 if layout == 2 else layout
             ctx.resize(W, H)
             ctx.set_arithmetic(capi.ARITH_FUSED if fused else capi.ARITH_SEPARATE)

@@ -749,6 +749,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                                pw ? c->d_pw_heads + (size_t)cb * 8 * 64 : (unsigned*)nullptr);
             VR_HIP(c, hipGetLastError());
             o.has_items = false;
+#if VR_EXPERIMENTAL_FLAVOURS
             if (fl == 14 && c->h_items && c->h_split) {
                 const int oi = (int)(c->order_seq % kOrderRing);
                 if (2 * (size_t)grid.x > o.items_cap) {
@@ -765,6 +766,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 VR_HIP(c, hipGetLastError());
                 o.has_items = true;
             }
+#endif
             VR_HIP(c, hipEventRecord(o.sorted, c->order_stream));
             o.valid = true;
         }
@@ -1034,7 +1036,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_FLAVOUR")) {
         const int f = atoi(e);
-        if (f >= 0 && f <= 16 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9))) c->default_flavour = f;
+        if (f >= 0 && f <= 17 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9 || f == 14 || f == 15))) c->default_flavour = f;
     }
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
@@ -1670,8 +1672,8 @@ int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     if (flavour < 0 || flavour > 17) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
-    if (!VR_EXPERIMENTAL_FLAVOURS && (flavour == 2 || flavour == 3 || flavour == 4 || flavour == 5 || flavour == 9))
-        return fail(c, VR_ERR_UNSUPPORTED, "vr_set_kernel_flavour: flavours 2, 3, 4, 5 and 9 are compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
+    if (!VR_EXPERIMENTAL_FLAVOURS && (flavour == 2 || flavour == 3 || flavour == 4 || flavour == 5 || flavour == 9 || flavour == 14 || flavour == 15))
+        return fail(c, VR_ERR_UNSUPPORTED, "vr_set_kernel_flavour: flavours 2, 3, 4, 5, 9, 14 and 15 are compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
     c->flavour = flavour;
     return VR_OK;
 }

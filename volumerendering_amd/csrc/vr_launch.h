@@ -7,14 +7,17 @@
 #include "vr_kernels.h"
 #include "vr_dp.h"
 #include "vr_pw.h"
-#include "vr_mixed.h"
-#include "vr_lt.h"
-// Kernel forms that lost every A/B -- flavours 2 / 3 (register-staged LDS wave tiles), 4 (closed-form leaping),
-// 5 (skipping without runs), 9 (one lane per ray, pipelined corner loads) and layout 2 (gradients on the fly) -- are compiled
-// only with -DVR_EXPERIMENTAL_FLAVOURS=1 (VR_EXPERIMENTAL_FLAVOURS=1 in the environment of build.py): a third fewer march
-// kernel instantiations in the shipped library.  Without them vr_set_kernel_flavour / vr_set_volume_layout reject those values.
+// Kernel forms that lost every A/B -- flavours 2 / 3 (register-staged LDS wave tiles), 4
+// (closed-form leaping), 5 (skipping without runs), 9 (one lane per ray, pipelined corner loads), 14 (lanes per ray chosen per
+// packet), 15 (LDS tiles by LDS-DMA) and layout 2 (gradients on the fly) -- are compiled only with -DVR_EXPERIMENTAL_FLAVOURS=1
+// (VR_EXPERIMENTAL_FLAVOURS=1 in the environment of build.py): half the march kernel instantiations of the shipped library.
+// Without them vr_set_kernel_flavour / vr_set_volume_layout reject those values.
 #ifndef VR_EXPERIMENTAL_FLAVOURS
 #define VR_EXPERIMENTAL_FLAVOURS 0
+#endif
+#if VR_EXPERIMENTAL_FLAVOURS
+#include "vr_mixed.h"
+#include "vr_lt.h"
 #endif
 #if !VR_FUSED && VR_EXPERIMENTAL_FLAVOURS
 #include "vr_wtb.h"
@@ -152,6 +155,7 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 #undef VR_LAUNCH_PW
 }
 
+#if VR_EXPERIMENTAL_FLAVOURS
 // lanes per ray per packet (vr_mixed.h)
 template <int V>
 void launch_mixed(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
@@ -167,10 +171,12 @@ void launch_mixed(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
     if (L.off32) hipLaunchKernelGGL((march_mixed_kernel<V, true, false>), L.grid, L.block, 0, s, B, L.mixed_items, L.n_logical);
     else hipLaunchKernelGGL((march_mixed_kernel<V, false, false>), L.grid, L.block, 0, s, B, L.mixed_items, L.n_logical);
 }
+#endif
 
 void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 {
     const int variant = L.variant;
+#if VR_EXPERIMENTAL_FLAVOURS
     if (L.lt) {  // LDS tiles (vr_lt.h): lit shader
         const bool skip = B.frame[0].brick_dist != nullptr;
         if (L.off32) {
@@ -194,6 +200,7 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         }
         return;
     }
+#endif
     if (L.pw) {
         switch (variant) {
         case VR_VARIANT_BASIC: launch_pw<V_BASIC>(L, s, B); break;
