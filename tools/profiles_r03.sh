@@ -20,6 +20,7 @@ $B --arith fused > $OUT/c3_fused.json 2> $OUT/c3_fused.err; echo "c3 fused rc $?
 $B --identical-frames > $OUT/c3_identical.json 2> $OUT/c3_identical.err; echo "c3 identical rc $?"
 $B --flavour 12 > $OUT/c3_f12.json 2> $OUT/c3_f12.err; echo "c3 f12 rc $?"
 $B --flavour 13 > $OUT/c3_f13.json 2> $OUT/c3_f13.err; echo "c3 f13 rc $?"
+# (flavours 14 and 15 need the experimental build: VR_EXPERIMENTAL_FLAVOURS=1 python -c "from volumerendering_amd import build; build.build_all()")
 $B --flavour 14 > $OUT/c3_f14.json 2> $OUT/c3_f14.err; echo "c3 f14 rc $?"
 $B --flavour 15 > $OUT/c3_f15.json 2> $OUT/c3_f15.err; echo "c3 f15 rc $?"
 $B --tf thin > $OUT/c3_thin.json 2> $OUT/c3_thin.err; echo "c3 thin rc $?"
