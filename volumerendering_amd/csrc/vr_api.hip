@@ -422,7 +422,10 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         }
         chain_known = chain;
         const bool short_chains = chain != 0 && chain - 1 < 128;
-        fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 1.2 ? 11 : 10);
+        // (two lanes per ray from 2 rays per lane on, four below: re-measured on the bricked layout -- a rank's quarter of C3
+        // (1.6 rays per lane), one frame at a time: 0.274 ms with two lanes, 0.203 with four; a rank's half (3.2): 0.362 / 0.377;
+        // a quarter with two launches in flight counts 3.2 and keeps two lanes: 0.190 / 0.217 per frame)
+        fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 2.0 ? 11 : 10);
     }
     // persistent wavefronts (12; vr_pw.h) exist for launches of one frame
     if ((fl == 12 || fl == 13 || fl == 16 || fl == 17) && n_frames != 1) fl = 6;
