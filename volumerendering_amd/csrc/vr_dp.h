@@ -163,6 +163,15 @@ __device__ __forceinline__ void march_dp_body(const MarchParams& P, const PixelS
         if constexpr (PIPE) asm volatile("" : "+v"(D));
     }
     const int lim = min(n_inside, P.steps_count);  // runs stay inside the provably-in-box prefix
+    // steps every marching ray of the wavefront is certainly inside the box for (wave-uniform): before that step the box test
+    // below is skipped by a scalar branch instead of being evaluated into an empty lane mask every round (vr_pw.h)
+    int n_in_w;
+    {
+        int v = alive ? n_inside : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+        n_in_w = __builtin_amdgcn_readfirstlane(v);
+    }
     float leap_c = 0.0f;
     if constexpr (SKIP) {
         const float vmax = fmaxf(fmaxf(fabsf(step.x) * P.bsx, fabsf(step.y) * P.bsy), fabsf(step.z) * P.bsz);
@@ -220,7 +229,7 @@ __device__ __forceinline__ void march_dp_body(const MarchParams& P, const PixelS
         // this slot's step
         const bool valid = alive && my < P.steps_count;
         bool inb = valid, gone = false;
-        if (my >= n_inside) {
+        if (base + K > n_in_w && my >= n_inside) {
             inb = valid && p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
             // p moves monotonically per component: once past the far bound it never returns
             gone = valid && !inb &&
