@@ -545,7 +545,8 @@ def main():
             return g
         if mg is not None:
             # the C++ loop: every rank renders its tiles, ncclGather, the root's output pass; two buffer sets, so up to two
-            # launches are in flight -- nbuf = 1 waits for every frame before the next one is enqueued
+            # launches are in flight -- nbuf = 1: one frame at a time ON THE DEVICE (vr_mgpu_set_frames_in_flight(1), set by
+            # timed_leg: every stage of a launch on one stream), the host enqueues ahead as the one-GPU leg does
             if fpl > 1 and nbuf > 1:
                 while g < end:
                     k = min(fpl, end - g)
@@ -560,8 +561,6 @@ def main():
                 b = mg.frame_async(variant)
                 last_single[b] = g % n_seq
                 g += 1
-                if nbuf == 1:
-                    mg.wait()
             mg.wait()
             return g
         while g < end:  # gloo rehearsal: synchronous, through host memory
@@ -582,6 +581,8 @@ def main():
         over ranks of the wall time.  Returns (seconds, kernel durations of the timed launches [+ extra frames up to
         min_events], composited samples of the K timed frames, fetched samples of them)."""
         ctx.hint_frames_in_flight(nbuf)  # what this leg's caller does: steers the default kernel choice (vr.h)
+        if mg is not None:
+            mg.set_frames_in_flight(1 if nbuf == 1 else 0)
         g = run_frames(0, n_warm, nbuf, fpl, present)
         sync_all()
         ctx.reset_kernel_times()

@@ -123,6 +123,13 @@ int vr_mgpu_download_present(vr_mgpu* m, int which, int frame_in_launch, uint8_t
  * on the root / sent), ms[2] = output (un-permute and / or present on the root; ~0 elsewhere), ms[3] = start .. end.
  * vr_mgpu_set_stage_timing drains the pipeline.                                                                    */
 int vr_mgpu_set_stage_timing(vr_mgpu* m, int enabled);
+
+/* frames == 1: ONE FRAME AT A TIME on the device -- the reference's interactive loop, App/src/Application.cpp:332-379: every
+ * rank's march, gather and (on the root) output pass go onto one stream, so a launch starts behind the last stage of the launch
+ * before it by stream order, and the host may keep enqueueing ahead instead of waiting between two frames.  Any other value: the
+ * default -- as many launches in flight as there are buffer sets (march on a stream per buffer set, gather and output on the
+ * communication stream).  Drains the pipeline.                                                                              */
+int vr_mgpu_set_frames_in_flight(vr_mgpu* m, int frames);
 int vr_mgpu_stage_times(vr_mgpu* m, int local_rank, int which, float ms[4]);
 
 #ifdef __cplusplus

@@ -213,3 +213,38 @@ def test_root_presents_through_the_permutation(lib, world):
             m.stage_times(0, b)
         with pytest.raises(capi.VrError):
             m.set_output(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 3])
+def test_one_frame_at_a_time_on_the_device(lib, world):
+    """vr_mgpu_set_frames_in_flight(1): march, gather and output pass of every launch on one stream per rank -- launches
+    enqueued back to back with no wait between them run one after the other on the device; the frames are the single-GPU
+    frames in both modes, and switching back and forth drains cleanly."""
+    W, H = 200, 150
+    yaws = [0.3, 1.2, 2.0, 2.6]
+    step, count = hr.stepping_params(24, 24, 24)
+    us = [vt.to_capi_uniforms(hr.make_uniforms(W, H, steps_count=count, step_size=step, yaw=y)) for y in yaws]
+    refs = []
+    with capi.Context(W, H, 0) as ctx:
+        scene(ctx, W, H, capi.LIGHT)
+        for u in us:
+            ctx.set_uniforms(u)
+            ctx.render(capi.LIGHT)
+            refs.append(ctx.download()[0])
+    with mgpu.MultiGpu.local(W, H, [0] * world, _lib=lib) as m:
+        for r in range(world):
+            scene(m.context(r), W, H, capi.LIGHT)
+        for mode in (1, 0, 1):
+            m.set_frames_in_flight(mode)
+            used = []
+            for g in (0, 1):          # two launches back to back: buffer sets 0 and 1
+                for r in range(world):
+                    m.context(r).set_uniforms(us[2 * (mode & 1) + g])
+                used.append(m.frame_async(capi.LIGHT))
+            m.wait()
+            assert used[0] != used[1]
+            for g, b in enumerate(used):
+                assert np.array_equal(vt.bits(m.download(b, W, H)), vt.bits(refs[2 * (mode & 1) + g])), (mode, g)
+        with pytest.raises(capi.VrError):
+            m.set_frames_in_flight(-1)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# multi-GPU loop: one frame at a time on one stream per rank (no host wait, no cross-stream waits): tests, then the shares
+set -x
+O=gpurun_out/r5f
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_mgpu_loopback_gpu.py tests/test_mgpu_gpu.py -x -q > $O/pytest.txt 2>&1
+rc=$?
+tail -3 $O/pytest.txt
+[ $rc -eq 0 ] || exit $rc
+for N in 2 4 8; do
+  VR_BENCH_SELF_GATHER=1 VR_MGPU_EXP_SHARE=$N timeout -k 10 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-regimes --no-live-pmc > $O/c3_share$N.json 2> $O/c3_share$N.err || { tail -5 $O/c3_share$N.err; exit 1; }
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r5f/*.json')):
+    d=json.load(open(f)); p=d.get('pipelined_one_frame_per_launch') or {}
+    print(f.split('/')[-1], 'serial', d['serial']['ms_per_step'], d['serial'].get('kernel_ms_median'), 'fl', d['config'].get('kernel_flavour_resolved'), '2x1', p.get('ms_per_step'), 'ovl', d['overlapped']['ms_per_step'], 'present', (d.get('serial_with_present') or {}).get('ms_per_step'))
+PY

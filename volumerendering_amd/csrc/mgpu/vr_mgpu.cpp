@@ -49,6 +49,7 @@ struct vr_mgpu {
     size_t seg_floats = 0;  // floats per rank segment = max tiles per rank * 64 * 64 * 4
     std::vector<Rank> r;    // the ranks this process drives
     int slots = 2;          // launches in flight (buffer sets in use)
+    bool one_stream = false;  // vr_mgpu_set_frames_in_flight(1): march, gather and output pass of every launch on ONE stream per rank
     int batch_cap = 1;      // frames per launch the buffer sets are sized for (grown on demand by vr_mgpu_frames_async)
     int exp_share = 1;      // experiment (VR_MGPU_EXP_SHARE=N, world of one only): render and gather only rank 0's share of an
                             // N-rank partition -- the timeline of one rank of an N-GPU run on a one-GPU box; frames are incomplete
@@ -310,18 +311,23 @@ static int enqueue_frames_impl(vr_mgpu* m, int variant, int n_frames, const vr_u
     //    communication stream touches, in order)
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
-        if (k.used[b]) MG_HIP(m, hipStreamWaitEvent(k.s_render[b], k.ev_gathered[b], 0));
-        if (m->stage_timing) MG_HIP(m, hipEventRecord(k.tm_t0[b], k.s_render[b]));
+        // (one frame at a time: the communication stream carries the march as well -- stream order instead of three event waits
+        // across streams per frame, and the host need not wait between two frames to keep them apart)
+        const hipStream_t s_render = m->one_stream ? k.s_comm : k.s_render[b];
+        if (k.used[b] && !m->one_stream) MG_HIP(m, hipStreamWaitEvent(s_render, k.ev_gathered[b], 0));
+        if (m->stage_timing) MG_HIP(m, hipEventRecord(k.tm_t0[b], s_render));
         if (uniforms) {
             void* ptrs[kBatch];
             for (int f = 0; f < n_frames; ++f) ptrs[f] = k.tiles[b] + (size_t)f * seg;
-            MG_VR(m, k, vr_render_tiles_batch_async(k.ctx, variant, k.rank, part_world, n_frames, uniforms, ptrs, k.s_render[b]));
+            MG_VR(m, k, vr_render_tiles_batch_async(k.ctx, variant, k.rank, part_world, n_frames, uniforms, ptrs, s_render));
         } else {
-            MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, part_world, k.tiles[b], k.s_render[b]));
+            MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, part_world, k.tiles[b], s_render));
         }
-        if (m->stage_timing) MG_HIP(m, hipEventRecord(k.tm_r[b], k.s_render[b]));
-        MG_HIP(m, hipEventRecord(k.ev_render[b], k.s_render[b]));
-        MG_HIP(m, hipStreamWaitEvent(k.s_comm, k.ev_render[b], 0));
+        if (m->stage_timing) MG_HIP(m, hipEventRecord(k.tm_r[b], s_render));
+        if (!m->one_stream) {
+            MG_HIP(m, hipEventRecord(k.ev_render[b], s_render));
+            MG_HIP(m, hipStreamWaitEvent(k.s_comm, k.ev_render[b], 0));
+        }
     }
     // 2. one gather: rank r's n_frames segments land back to back at gathered[b] + r * n_frames * seg on the root.  Every
     //    rank's communication stream carries the launches in the same order, so the collectives match up across ranks.
@@ -535,6 +541,15 @@ int vr_mgpu_set_stage_timing(vr_mgpu* m, int enabled)
     m->stage_timing = enabled != 0;
     for (auto& k : m->r)
         for (int b = 0; b < kSlots; ++b) k.tm_valid[b] = false;
+    return VR_OK;
+}
+
+int vr_mgpu_set_frames_in_flight(vr_mgpu* m, int frames)
+{
+    if (!m || frames < 0 || frames > kSlots) return VR_ERR_INVALID_ARG;
+    int rc = vr_mgpu_wait(m);
+    if (rc != VR_OK) return rc;
+    m->one_stream = frames == 1;
     return VR_OK;
 }
 

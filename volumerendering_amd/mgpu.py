@@ -17,7 +17,7 @@ ABI_SYMBOLS = ["vr_mgpu_unique_id", "vr_mgpu_create", "vr_mgpu_create_local", "v
                "vr_mgpu_world", "vr_mgpu_local_ranks", "vr_mgpu_context", "vr_mgpu_frame_async", "vr_mgpu_wait",
                "vr_mgpu_frame_device_ptr", "vr_mgpu_download", "vr_mgpu_reduce", "vr_mgpu_backend", "vr_mgpu_frames_async",
                "vr_mgpu_batch_frame_device_ptr", "vr_mgpu_download_batch_frame", "vr_mgpu_comm_count", "vr_mgpu_device",
-               "vr_mgpu_set_output", "vr_mgpu_present_device_ptr", "vr_mgpu_download_present", "vr_mgpu_set_stage_timing",
+               "vr_mgpu_set_output", "vr_mgpu_present_device_ptr", "vr_mgpu_download_present", "vr_mgpu_set_stage_timing", "vr_mgpu_set_frames_in_flight",
                "vr_mgpu_stage_times"]
 
 OUT_FRAME, OUT_PRESENT = 1, 2
@@ -61,6 +61,7 @@ def bind(path: str) -> C.CDLL:
     lib.vr_mgpu_present_device_ptr.restype = vp
     lib.vr_mgpu_download_present.argtypes = [vp, i32, i32, vp]
     lib.vr_mgpu_set_stage_timing.argtypes = [vp, i32]
+    lib.vr_mgpu_set_frames_in_flight.argtypes = [vp, i32]
     lib.vr_mgpu_stage_times.argtypes = [vp, i32, i32, C.POINTER(C.c_float * 4)]
     return lib
 
@@ -181,6 +182,11 @@ class MultiGpu:
 
     def set_stage_timing(self, enabled: bool):
         self._chk(self.lib.vr_mgpu_set_stage_timing(self.h, 1 if enabled else 0))
+
+    def set_frames_in_flight(self, frames: int):
+        """1: one frame at a time on the device (march, gather and output pass of every launch on one stream per rank; the host
+        may enqueue ahead); anything else: as many launches in flight as there are buffer sets."""
+        self._chk(self.lib.vr_mgpu_set_frames_in_flight(self.h, frames))
 
     def stage_times(self, local_rank: int, which: int):
         """(march, gather, output, total) ms of the last launch into buffer set `which` on local rank `local_rank`."""
