@@ -185,7 +185,7 @@ __device__ __forceinline__ bool p2_vote(const MarchParams& P, bool sampled, floa
 // SKIP: empty-space skipping on top of it.  One distance-field byte per ray rides along with each corner buffer: the byte of
 // the exact position whose corners are in flight, asked for just ahead of them and read a trip later.  It says whether the
 // step blends (an inert brick: the identity, march_packet's test), whether the two steps after it need their corners at all
-// (three bricks from anything active: the requests get offsets out of range), and how many steps after it every ray of the
+// (the ray's safe steps in inert bricks reach them: its lanes are switched off for those loads), and how many steps after it every ray of the
 // packet can skip: then the REQUESTS jump (4 .. 64 rounded additions, the identity steps of march_packet's runs) while the two
 // steps already in flight are still being consumed -- nothing in flight is thrown away and no latency is exposed.  A step in
 // which no ray blends interpolates nothing; the per-step vote (every opacity zero for certain: no texels, no gradient, no
