@@ -132,7 +132,7 @@ struct vr_ctx {
     int default_flavour = 0;  // what flavour 0 resolves to (experiment knob VR_EXP_FLAVOUR)
     int last_flavour = 0;     // the flavour the last launch resolved to
     bool last_otf = false;    // ... and whether it derived the gradients from the density plane
-    int xcd_mode = 1;         // deal a tile's workgroups over the XCDs (VR_EXP_XCD=0: one XCD per tile)
+    int xcd_mode = 2;         // deal a tile's 16x16 sub-blocks over the XCDs (VR_EXP_XCD=1: its packets one by one; 0: one XCD per tile)
     bool pw_ltf = true;       // persistent wavefronts keep TF slot 0 in LDS (VR_EXP_PW_LTF=0: from L1, for A/B)
     unsigned p2_threads = 0;  // flavours 16 / 17: threads per workgroup when not 768 (VR_EXP_P2_THREADS: fewer wavefronts per CU)
     bool pw_steal = false;    // ... and take other classes' packets once their own class is exhausted (VR_EXP_PW_STEAL=1: measured
