@@ -380,6 +380,11 @@ def main():
                     help="batched leg: frames marched by one launch (vr_render_batch_async / vr_mgpu_frames_async; 1..4, 0 = 4)")
     ap.add_argument("--identical-frames", action="store_true",
                     help="experiment: every frame with frame 0's camera (what rounds 1-2 measured) instead of the turntable")
+    ap.add_argument("--turn-frames", type=int, default=628,
+                    help="frames of the full-turn leg (one frame at a time, yaw + 0.01 rad per frame: 628 = 2 pi; 0 = skip)")
+    ap.add_argument("--settle", type=int, default=24,
+                    help="untimed frames in front of every leg's warm-up: the context measures its candidate kernels on live frames "
+                         "(vr.h, flavour 0) and the leg then times the steady state")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-identical", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -583,6 +588,9 @@ def main():
         ctx.hint_frames_in_flight(nbuf)  # what this leg's caller does: steers the default kernel choice (vr.h)
         if mg is not None:
             mg.set_frames_in_flight(1 if nbuf == 1 else 0)
+        if args.settle > 0:  # (untimed, and in front of the W warm-up frames: the leg itself is W + K frames from camera 0)
+            run_frames(0, args.settle, nbuf, fpl, present)
+            sync_all()
         g = run_frames(0, n_warm, nbuf, fpl, present)
         sync_all()
         ctx.reset_kernel_times()
@@ -630,6 +638,56 @@ def main():
     res_pipe = timed_leg(nbuf_over, args.warmup, args.steps) if (fpl > 1 and nbuf_over > 1) else None
     # ... and the throughput leg proper: two launches in flight, fpl frames per launch, fpl different cameras
     res_over = timed_leg(nbuf_over, args.warmup, args.steps, fpl=fpl)
+
+    # ---- SURVEY 8d's t_frame, literally: >= 20 SYNCHRONOUS vr_render calls (the host waits for every frame), each timed by the
+    # HIP events vr_render records around the frame on its stream; 3 warm-ups; the median.  Beside it: the stream-ordered
+    # `serial` leg above (the host enqueues ahead and never waits inside the timed region), whose wall / K is `value`.
+    sync_8d = None
+    if not multi:
+        ctx.hint_frames_in_flight(1)
+        n_sync = max(20, min(args.steps, 100))
+        tms, kms = [], []
+        for g in range(3 + n_sync):
+            ctx.set_uniforms(us[g % n_seq])
+            ctx.render(variant)
+            k_ms, t_ms = ctx.last_timing()
+            if g >= 3:
+                tms.append(t_ms)
+                kms.append(k_ms)
+        med = float(np.median(tms))
+        comp = [counts[g % n_seq][0] for g in range(3, 3 + n_sync)]
+        sync_8d = {"calls": n_sync, "warmup": 3, "t_frame_ms_median": round(med, 4), "t_frame_ms_p10_p90": [round(float(np.percentile(tms, 10)), 4), round(float(np.percentile(tms, 90)), 4)],
+                   "kernel_ms_median": round(float(np.median(kms)), 4), "fps": round(1e3 / med, 2),
+                   "value": round(float(np.median(comp)) / med / 1e6, 3),
+                   "note": "SURVEY 8d: median of hipEvent-timed synchronous vr_render calls (events on the frame's stream around ray set-up + march + "
+                           "record keeping), turntable cameras 3 .. 3 + calls; value = median composited samples / median t_frame"}
+
+    # ---- the full turn: one frame at a time, every camera of a 2 pi turntable (yaw + 0.01 rad per frame) -----------------------
+    full_turn = None
+    if not multi and args.turn_frames > 0 and not args.identical_frames:
+        ctx.hint_frames_in_flight(1)
+        us_t = camera_sequence(app, args.turn_frames, turntable=True)
+        comp_t = []
+        for u in us_t:  # untimed: what every camera composites
+            ctx.set_uniforms(u)
+            ctx.render_async(variant, frames[0].data_ptr(), streams[0])
+            comp_t.append(ctx.counters()[0])
+        torch.cuda.synchronize()
+        ctx.reset_kernel_times()
+        t0 = time.perf_counter()
+        for u in us_t:
+            ctx.set_uniforms(u)
+            ctx.render_async(variant, frames[0].data_ptr(), streams[0])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kt = ctx.kernel_times(256)
+        full_turn = {"frames": len(us_t), "yaw_step_rad": 0.01, "ms_per_frame_mean": round(dt / len(us_t) * 1e3, 4),
+                     "value": round(sum(comp_t) / dt / 1e9, 3), "fps": round(len(us_t) / dt, 2),
+                     "composited_samples_per_frame_min_max": [min(comp_t), max(comp_t)],
+                     "kernel_ms_last_256_p10_p50_p90": [round(float(np.percentile(kt, q)), 4) for q in (10, 50, 90)] if len(kt) else None,
+                     "kernel_flavour_resolved_last": ctx.last_kernel_flavour(),
+                     "note": "one frame at a time on one stream (as `serial`), the WHOLE turn: composited samples of all frames / wall time"}
+        ctx.set_uniforms(u0)
 
     # every frame the batched launches left behind must equal a single-frame render with the same uniforms, bit for bit
     batched_equal = None
@@ -863,8 +921,10 @@ def main():
                        "(App/src/Application.cpp:410-416, App/src/Camera.cpp:146-152); every leg renders frames 0 .. W+K-1; frames of "
                        "one batched launch have different uniforms"),
             "partition": part,
-            "value_is": "SURVEY 8d's t_frame leg: ONE FRAME AT A TIME on one stream (`serial`), composited samples of the K timed "
-                        f"turntable frames / wall time; the pipelined ({nbuf_over} launches x 1 frame) and batched ({nbuf_over} launches x "
+            "value_is": "the `serial` leg: ONE FRAME AT A TIME, stream-ordered on one stream (the host enqueues ahead and never waits inside "
+                        "the timed region), composited samples of the K timed turntable frames / wall time between barrier + synchronise.  "
+                        "SURVEY 8d's t_frame to the letter (median of hipEvent-timed synchronous vr_render calls) is `sync_8d`; every camera "
+                        f"of a 2 pi turn is `full_turn`; the pipelined ({nbuf_over} launches x 1 frame) and batched ({nbuf_over} launches x "
                         f"{fpl} frames) legs are extras, in `pipelined_one_frame_per_launch` / `overlapped`",
             "composited_samples_frame0": total_samples, "fetched_samples_frame0": total_fetched, "covered_pixels_frame0": covered,
             "composited_samples_per_frame_min_max": [min(c[0] for c in counts), max(c[0] for c in counts)],
@@ -877,6 +937,10 @@ def main():
         "serial": serial, "overlapped": over, "roofline": roofline,
     }
     out["config"]["arithmetic"] = args.arith
+    if sync_8d:
+        out["sync_8d"] = sync_8d
+    if full_turn:
+        out["full_turn"] = full_turn
     if with_present:
         out["serial_with_present"] = with_present
     if pipelined:

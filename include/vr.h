@@ -299,13 +299,19 @@ int vr_last_counters(vr_ctx* ctx, uint64_t out[3]);
  * in blockIdx order.  Writes min(capacity, n) records and returns n (the number of workgroups launched).      */
 int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
 
-/* Kernel flavour for A/B measurements.  All flavours are bit-identical in output and in the sample counts.
+/* Kernel flavour for A/B measurements.  All flavours are bit-identical in output and in the composited / covered counts; the
+ * FETCHED count (vr_last_counters out[2]) is the same for all but 1 and 16, which skip nothing and fetch every composited sample
+ * -- the default may pick 16 for volumes with next to nothing to skip, so `fetched` can differ between frames of one scene.
  * (2, 3, 4, 5 and 9 exist only in builds with -DVR_EXPERIMENTAL_FLAVOURS=1: vr_experimental_flavours below.)
- *   0  default: exact empty-space skipping + wave-uniform runs through inert bricks; lanes per ray chosen from
- *      what will be on the machine -- the size of the launch (frames per launch included) times the launches the
- *      caller keeps in flight (vr_hint_frames_in_flight) -- and from the longest ray chain of an earlier launch of the same scene: one lane
- *      per ray when the machine is full of rays or the chains are short, two or four when the frame would otherwise
- *      wait for its longest rays (small frames, one GPU's share of the tiles)
+ *   0  default: a MEASURED choice.  Every form below gives the same bits, so the context tries the eligible ones on the
+ *      caller's own frames -- three launches each (frames in flight + 3 with launches in flight), behind a few launches of the
+ *      prior's pick so that a launch order exists -- and keeps the fastest by the launches' own records (no synchronisation: the
+ *      sort behind a launch writes its duration to pinned memory).  Per "what is launched of what": shader, rank share, viewport,
+ *      frames per launch, vr_hint_frames_in_flight, volume / table uploads, arithmetic, layout; the trial re-opens when the
+ *      longest ray chain has moved by a quarter.  Candidates: the prior's pick (exact skipping; whole one-at-a-time frames of
+ *      the lit / unlit shader and the composite: 17, or 16 with nothing to skip; else lanes per ray from the launch size, the
+ *      frames in flight and the chain length of an earlier launch), 17 / 16, 6, and 10 / 11 (launches that leave the machine part
+ *      empty) or 12.  vr_kernel_choice reports what was measured.  VR_EXP_TUNE=0 in the environment: the prior alone.
  *   1  one lane per ray, no empty-space skipping (every composited sample is fetched)
  *   2 / 3  LDS wave tiles without / with skipping (lit shader only; others fall back to 1 / 6)
  *   4  skipping + closed-form leaping (f32 accumulation as integer arithmetic on the bit patterns)
@@ -318,17 +324,26 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *   12 / 13  persistent wavefronts (csrc/vr_pw.h): one workgroup of 16 wavefronts per CU, the packets come from a queue
  *      (eight heads, longest chains first), TF slot 0 is read from LDS; 13 also issues the next step's corner loads before
  *      this step's shading (lit / unlit shader).  Launches of one frame; fewer bytes through the texture addressers
- *   16  persistent wavefronts, NO skipping, corner loads two steps ahead (two corner buffers, 2 wavefronts per SIMD): for volumes
- *      with nothing to skip; lit / unlit shader with TF slot 0 in LDS and the bricked copy, else it runs as 13
- *   17  the same with exact empty-space skipping decided ahead of the loads (one distance-field byte per ray rides along with
- *      each corner buffer; idle rays' lanes are switched off for the loads; runs of identity steps become jumps of the requests
- *      while the steps in flight are consumed; 3 wavefronts per SIMD); else it runs as 12.  The default for whole frames of
- *      the lit / unlit shader whose longest ray chain is 200 .. 400 samples
+ *   16 / 17  persistent wavefronts with the corner loads TWO steps ahead (csrc/vr_p2.h): two corner buffers, the gather an indexed
+ *      buffer load of the voxel's slot in the bricked copy, the slot arithmetic of a cell from per-axis tables in LDS beside TF
+ *      slot 0.  16 skips nothing (volumes with nothing to skip; 2 wavefronts per SIMD); 17 decides the exact empty-space skipping
+ *      ahead of the loads (one distance-field byte per ray rides along with each corner buffer; idle rays' lanes are switched off
+ *      for the loads; runs of identity steps become jumps of the requests while the steps in flight are consumed; 3 per SIMD).
+ *      Lit / unlit shader and (17; 16 runs as 17) the three-volume composite, whose mask and dose are fetched on demand behind the
+ *      per-brick mask record; volumes of 4 GiB and more through a window of z-slabs of bricks that follows the packet; launches of
+ *      several frames take (frame, packet) items from the one queue.  Needs one table resolution <= 8190 and the bricked copy
+ *      (vr_set_volume_layout(0)); else 13 / 12, or 6 for launches of several frames
  *   14  (experimental build) lanes per ray chosen PER PACKET (csrc/vr_mixed.h): packets whose longest ray chain in an earlier
  *      launch of the same shape reached 75 % of that launch's longest are marched as two half packets with two lanes per ray,
  *      the rest with one; one-frame launches of the shaders that have a depth-parallel form
  *   15  (experimental build) LDS tiles filled by LDS-DMA (csrc/vr_lt.h): lit shader, launches of one frame          */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
+
+/* What the default's measured choice (flavour 0) knows about the launch shape it was asked for last: the candidates' flavours, the
+ * milliseconds per launch measured for each (0 = its trial has not been evaluated yet) and the index of the one kept (-1 = trial
+ * running: the prior's pick, flavours[0], runs meanwhile).  Returns the number of candidates (0: nothing launched through the
+ * default yet, or the shape has a single eligible form).                                                               */
+int vr_kernel_choice(vr_ctx* ctx, int flavours[4], float ms_per_launch[4], int* chosen);
 
 /* 1 if the library was built with -DVR_EXPERIMENTAL_FLAVOURS=1: the kernel forms that lost every A/B -- flavours 2, 3, 4, 5, 9,
  * 14, 15 and volume layout 2 -- are then compiled in; 0 (the shipped build): vr_set_kernel_flavour / vr_set_volume_layout return

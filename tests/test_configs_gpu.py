@@ -88,21 +88,41 @@ def test_c3_noisy_air_and_zero_prefix_tf_vs_oracle():
 
 @pytest.mark.parametrize("workload", ["C3", "C4"])
 def test_config_flavours_and_tile_partition_agree_at_full_size(workload):
-    """Size-independent properties at full size: every kernel flavour gives the same bits and counts as the plain
-    no-skipping kernel, and the image-tile partition (world 2 and 8) reassembles the single-GPU frame exactly."""
+    """Every kernel flavour, FORCED, at full size against the ORACLE's frame (and the plain no-skipping kernel's counts) --
+    the two-steps-ahead kernels (16 / 17: what the default picks for these frames) included, with the flavour that really ran
+    asserted so that a silent fallback cannot pass; and the image-tile partition (world 2 and 8) reassembles the single-GPU
+    frame exactly."""
     n, W, H, vname = wl.WORKLOADS[workload]
     with host.Application(W, H, 0) as app:
-        wl.build_scene(app, workload, "default", quiet=True)
+        variant, vols = wl.build_scene(app, workload, "default", quiet=True)
         ctx = app.context()
+        ref, n_ref, cov_ref = oracle_frame(app, variant, vols, W, H)
         ctx.set_kernel_flavour(1)
         base, n_base, cov_base, _ = gpu_frame(app)
-        for fl in (0, 6, 11, 10, 12):
+        assert_frame_equal(base, ref, (workload, 1))
+        assert (n_base, cov_base) == (n_ref, cov_ref)
+        for fl in (0, 6, 11, 10, 12, 13, 16, 17):
             ctx.set_kernel_flavour(fl)
-            frag, n_f, cov_f, _ = gpu_frame(app)
-            assert np.array_equal(vt.bits(frag), vt.bits(base)), (workload, fl)
-            assert (n_f, cov_f) == (n_base, cov_base), (workload, fl)
+            for rep in range(2 if fl else 5):  # (the default settles on its kernel after a few launches; every one is checked)
+                frag, n_f, cov_f, _ = gpu_frame(app)
+                assert_frame_equal(frag, ref, (workload, fl, rep))
+                assert (n_f, cov_f) == (n_ref, cov_ref), (workload, fl)
+            ran = ctx.last_kernel_flavour()
+            if fl in (6, 10, 11, 12):
+                assert ran == fl, (workload, fl, ran)
+            elif fl == 13:
+                assert ran == (13 if vname == "LIGHT" else 12) or ran == 13, (workload, fl, ran)
+            elif fl == 16:
+                assert ran == (17 if vname == "VOLUME_MASK" else 16), (workload, fl, ran)
+            elif fl == 17:
+                assert ran == 17, (workload, fl, ran)
+        # the same with two launches in flight announced (half-size workgroups, two per CU) and with the thin table
+        ctx.set_kernel_flavour(17)
+        ctx.hint_frames_in_flight(2)
+        frag, n_f, cov_f, _ = gpu_frame(app)
+        assert_frame_equal(frag, ref, (workload, "17 in flight"))
+        ctx.hint_frames_in_flight(1)
         ctx.set_kernel_flavour(0)
-        variant = capi.VARIANT_NAMES.index(vname)
         for world in (2, 8):
             tpr = tiles.tile_count(W, H, 0, world)
             gathered = np.zeros((world, tpr, tiles.TILE, tiles.TILE, 4), dtype=np.float32)
@@ -115,7 +135,10 @@ def test_config_flavours_and_tile_partition_agree_at_full_size(workload):
                 total += cnt
             assert total == n_base
             assert np.array_equal(vt.bits(tiles.unpack(gathered, W, H, world)), vt.bits(base)), (workload, world)
-        assert_batched_frames_equal(app, variant, W, H, base, n_base)
+        for fl in (0, 17):
+            ctx.set_kernel_flavour(fl)
+            assert_batched_frames_equal(app, variant, W, H, base, n_base)
+        ctx.set_kernel_flavour(0)
 
 
 def assert_batched_frames_equal(app, variant, W, H, frame, n_samples):
@@ -145,11 +168,14 @@ def test_c5_16gib_volume_64bit_addressing_vs_oracle():
         assert (n_gpu, cov_gpu) == (n_ref, cov_ref)
         del ref
         # no-skipping kernel and the depth-parallel kernels: same bits, same counts
-        for fl in (1, 11, 12):
+        # (`frag` has just been compared with the oracle: equality with it is equality with the oracle.  16 / 17: the moving gather
+        # window of march_p2_kernel, the volume being four windows long)
+        for fl in (1, 11, 12, 17, 16):
             ctx.set_kernel_flavour(fl)
             f2, n2, cov2, _ = gpu_frame(app)
             assert np.array_equal(vt.bits(f2), vt.bits(frag)), fl
             assert (n2, cov2) == (n_gpu, cov_gpu), fl
+            assert ctx.last_kernel_flavour() == fl, (fl, ctx.last_kernel_flavour())
         ctx.set_kernel_flavour(0)
         # one rank's share of an 8-GPU partition = the same pixels of the full frame
         world = 8
@@ -159,6 +185,9 @@ def test_c5_16gib_volume_64bit_addressing_vs_oracle():
             t, _ = ctx.download_tiles(nt)
             assert np.array_equal(vt.bits(t), vt.bits(tiles.pack(frag, r, world))), r
         assert_batched_frames_equal(app, variant, W, H, frag, n_gpu)   # the 64-bit-offset batch kernel
+        ctx.set_kernel_flavour(17)
+        assert_batched_frames_equal(app, variant, W, H, frag, n_gpu)   # ... and the persistent one's (frame, packet) queue
+        ctx.set_kernel_flavour(0)
         # thin TF (no ray terminates: the longest accumulation chains): every 16th 64x64 tile against the oracle
         wl.apply_tf(app, vname, "thin")
         app.OnUpdate()

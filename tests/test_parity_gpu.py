@@ -508,7 +508,7 @@ def test_two_frames_in_flight_on_two_streams(ctx):
         ctx.render(capi.LIGHT)
         ref2, _, n2 = ctx.download()
         assert n1 != n2
-        for fl in (0, 6, 10):
+        for fl in (0, 6, 10, 17, 16):
             ctx.set_kernel_flavour(fl)
             for k in range(8):  # same uniforms for a whole burst: they are read when the launch is enqueued
                 ctx.render_async(capi.LIGHT, bufs[k & 1].value, streams[k & 1].value)
@@ -796,7 +796,7 @@ def _batch_uniforms(W, H, count, step):
 
 
 @pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.VOLUME_MASK, capi.MULTI_CTRT])
-@pytest.mark.parametrize("flavour", [0, 1, 6, 10, 11])
+@pytest.mark.parametrize("flavour", [0, 1, 6, 10, 11, 16, 17])
 def test_frames_of_one_launch_equal_single_renders(ctx, variant, flavour):
     """vr_render_batch_async: n = 1..4 frames of the same scene marched by ONE grid, each with its own uniforms and output
     buffer, are bit-equal to vr_render with those uniforms (which the other tests pin to the oracle); the counters reported
@@ -1012,7 +1012,7 @@ def test_persistent_wavefronts_block_records(ctx):
         ctx.resize(96, 80)
 
 
-# ---- two steps ahead (flavours 16 / 17, csrc/vr_pw.h: march_p2_kernel) ------------------------------------------------------------
+# ---- two steps ahead (flavours 16 / 17, csrc/vr_p2.h: march_p2_kernel; more in tests/test_p2_gpu.py) ------------------------------------------------------------
 @pytest.mark.parametrize("variant", [capi.LIGHT, capi.BASIC])
 def test_two_steps_ahead_jumps_idle_rays_and_the_last_steps(ctx, variant):
     """The two-steps-ahead kernels where their own machinery is exercised most: a small dense body in a large empty volume (jumps

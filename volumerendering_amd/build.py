@@ -33,7 +33,7 @@ def build_hip(force: bool = False) -> str:
     """Two translation units, compiled side by side: vr_api.hip (C ABI + kernels with separately rounded multiply-adds)
     and vr_fused.hip (the march kernels once more with fused multiply-adds), linked into one libvr_hip.so."""
     target = os.path.join(HERE, "libvr_hip.so")
-    hdrs = [os.path.join(CSRC, f) for f in ("vr_kernels.h", "vr_wtb.h", "vr_dp.h", "vr_pw.h", "vr_mixed.h", "vr_lt.h", "vr_device.h", "vr_launch.h")]
+    hdrs = [os.path.join(CSRC, f) for f in ("vr_kernels.h", "vr_wtb.h", "vr_dp.h", "vr_pw.h", "vr_p2.h", "vr_mixed.h", "vr_lt.h", "vr_device.h", "vr_launch.h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "vr.h"))
     flags = [f for f in HIP_FLAGS if f != "-shared"] + os.environ.get("VR_EXTRA_HIPCC_FLAGS", "").split()
     if os.environ.get("VR_EXPERIMENTAL_FLAVOURS", "0") not in ("", "0"):

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "vr_render_batch_async", "vr_render_tiles_batch_async", "vr_unpack_tiles_strided_async",
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
     "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream", "vr_hint_frames_in_flight",
-    "vr_set_kernel_timing", "vr_present_tiles_async", "vr_last_split_packets", "vr_experimental_flavours",
+    "vr_set_kernel_timing", "vr_present_tiles_async", "vr_last_split_packets", "vr_experimental_flavours", "vr_kernel_choice",
 ]
 
 
@@ -124,6 +124,7 @@ def load() -> C.CDLL:
     lib.vr_present_async.argtypes = [vp, vp, vp, vp]
     lib.vr_present_tiles_async.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.vr_hint_frames_in_flight.argtypes = [vp, i32]
+    lib.vr_kernel_choice.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.vr_stream.argtypes = [vp, i32]
     lib.vr_stream.restype = vp
     lib.vr_volume_layout.argtypes = [vp, i32, C.POINTER(C.c_int)]
@@ -319,6 +320,14 @@ class Context:
 
     def last_kernel_flavour(self) -> int:
         return self._chk(self.lib.vr_last_kernel_flavour(self.h))
+
+    def kernel_choice(self):
+        """(candidate flavours, ms per launch measured for each, index of the one kept or -1) of the default's measured choice."""
+        fl, ms, ch = (C.c_int * 4)(), (C.c_float * 4)(), C.c_int(-1)
+        n = self.lib.vr_kernel_choice(self.h, fl, ms, C.byref(ch))
+        if n < 0:
+            self._chk(n)
+        return [int(x) for x in fl[:n]], [float(x) for x in ms[:n]], int(ch.value)
 
     def hint_frames_in_flight(self, frames: int):
         """How many frames the caller keeps in flight on different streams (steers the default kernel choice only)."""

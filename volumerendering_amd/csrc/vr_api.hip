@@ -107,7 +107,24 @@ struct vr_ctx {
     unsigned last_split = 0;      // packets the last mixed launch marched with two lanes per ray
     unsigned long long* h_span = nullptr;  // pinned, kRing words: duration of launch q in 100 MHz ticks + 1, from its records (0 = not known)
     bool ring_events[kRing] = {};          // launch q was timed with the events k0 / k1 instead (no sort behind it)
+    unsigned long long* h_end = nullptr;   // pinned, kRing words: end of launch q's last workgroup on the 100 MHz device clock, | 1 (0 = not known)
     unsigned* h_chain = nullptr;  // pinned, one word per ring slot: longest ray chain + 1 of that launch (0 = not known yet)
+    // Measured kernel choice (flavour 0): every kernel form is bit-identical, so the context tries the eligible ones on
+    // the caller's own frames and keeps the fastest by the launches' own records -- per "what is launched of what".
+    struct Tune {
+        unsigned long long key = 0;   // shader, share, viewport, frames per launch, frames in flight, scene epoch, arithmetic, layout (0 = free)
+        int n = 0, cand[4] = {};      // the eligible flavours; cand[0] = the prior's pick (what runs while nothing is known)
+        int cur = 0, issued = 0;      // candidate on trial, launches it has had
+        int per = 3, settle = 4;      // launches per candidate; launches before the trial starts (no launch order exists yet)
+        long long launch0[4] = {};    // ring.head of each candidate's first trial launch
+        int choice = -1;              // index into cand of the kernel kept (-1 = trial running)
+        unsigned chain_ref = 0;       // longest ray chain + 1 when it was chosen: the trial re-opens when that has moved by a quarter
+        float cost[4] = {};           // ms per launch measured (0 = no data)
+        unsigned long long used = 0;  // (least recently used slot is recycled)
+    } tune[8];
+    unsigned long long tune_clock = 0;
+    unsigned long long tf_epoch = 0;  // bumped by every table upload
+    int tune_mode = 1;                // VR_EXP_TUNE=0: the prior alone (round 3's thresholds)
     int frames_in_flight = 1;                 // vr_hint_frames_in_flight: frames the caller keeps in flight on different streams
     unsigned long long order_seq = 0;
     hipStream_t flight[kStreams] = {};  // vr_stream(): streams probed to run side by side (created on first use)
@@ -135,6 +152,11 @@ struct vr_ctx {
     int xcd_mode = 2;         // deal a tile's 16x16 sub-blocks over the XCDs (VR_EXP_XCD=1: its packets one by one; 0: one XCD per tile)
     bool pw_ltf = true;       // persistent wavefronts keep TF slot 0 in LDS (VR_EXP_PW_LTF=0: from L1, for A/B)
     unsigned p2_threads = 0;  // flavours 16 / 17: threads per workgroup when not 768 (VR_EXP_P2_THREADS: fewer wavefronts per CU)
+    unsigned p2_wgs = 0;      // flavours 16 / 17: workgroups per CU when not chosen by the launch (VR_EXP_P2_WGS)
+    int p2_dynq = 0;          // flavours 16 / 17: every item from the queue heads, the wavefronts' first ones too (VR_EXP_P2_DYNQ=1; measured with
+                              // launches in flight, where workgroups start as others retire: 0.522 against 0.502 ms per C3 frame, so off)
+    unsigned p2_window = 0;   // flavours 16 / 17: records per gather window (VR_EXP_P2_WINDOW: the moving window of volumes >= 4 GiB, forced
+                              // onto small volumes by the tests; 0 = what the hardware reaches, just below 4 GiB)
     bool pw_steal = false;    // ... and take other classes' packets once their own class is exhausted (VR_EXP_PW_STEAL=1: measured
                               // 2-4 % slower -- the classes are even when a tile's packets are dealt over them)
     double active_fraction = 1.0;  // share of bricks that are not inert, of the distance field in use
@@ -302,6 +324,108 @@ void fill_frame_params(MarchParams& P, const vr_uniforms& u)
     }
 }
 
+// The measured kernel choice (flavour 0).  `cand[0 .. n)` are the flavours that may run this launch (cand[0] = the prior's pick); returns
+// the one to launch now.  A trial gives every candidate `per` launches in turn -- after `settle` launches of the prior, so that a
+// launch order exists (the trial then measures what the steady state runs) -- and reads the launches' durations from
+// the pinned words their sorts fill (no synchronisation: a trial is evaluated when its last word has arrived; until then the
+// prior runs).  One launch at a time: the shortest first-start-to-last-end span of a candidate's launches but its first.  Launches
+// in flight: the mean interval between the ends of its consecutive launches (each of which ran beside launches of the same
+// candidate only: the first and the last one of a candidate's turn are not used).  The trial re-opens when the scene, the tables,
+// the launch shape or the frames-in-flight hint change (the key) and when the longest ray chain has moved by a quarter.
+int tune_pick(vr_ctx* c, unsigned long long key, const int* cand, int n, unsigned chain_now, bool measurable)
+{
+    if (n <= 1) return cand[0];
+    vr_ctx::Tune* t = nullptr;
+    for (auto& e : c->tune)
+        if (e.key == key) t = &e;
+    const int in_flight = c->frames_in_flight;
+    auto reset = [&](vr_ctx::Tune& e, int first) {
+        e.key = key;
+        e.n = 0;
+        e.cand[e.n++] = first;
+        for (int i = 0; i < n; ++i)
+            if (cand[i] != first && e.n < 4) e.cand[e.n++] = cand[i];
+        e.cur = 0;
+        e.issued = 0;
+        e.per = in_flight > 1 ? in_flight + 3 : 3;
+        e.settle = in_flight + 3;
+        e.choice = -1;
+        e.chain_ref = 0;
+        for (int i = 0; i < 4; ++i) {
+            e.cost[i] = 0.0f;
+            e.launch0[i] = -1;
+        }
+    };
+    if (!t) {
+        t = &c->tune[0];
+        for (auto& e : c->tune)
+            if (e.used < t->used) t = &e;
+        reset(*t, cand[0]);
+    } else {
+        // the eligible set may have changed under the same key (a flavour knob, a table that fits LDS no more)
+        bool same = t->n == n;
+        for (int i = 0; i < n && same; ++i) {
+            bool found = false;
+            for (int j = 0; j < t->n; ++j) found = found || t->cand[j] == cand[i];
+            same = found;
+        }
+        if (!same) reset(*t, cand[0]);
+    }
+    t->used = ++c->tune_clock;
+    if (t->choice >= 0) {
+        if (chain_now != 0 && t->chain_ref != 0) {
+            const unsigned lo = t->chain_ref - t->chain_ref / 4, hi = t->chain_ref + t->chain_ref / 4;
+            if (chain_now < lo || chain_now > hi) reset(*t, t->cand[t->choice]);  // (the kernel kept so far runs while the new trial settles)
+        }
+        if (t->choice >= 0) return t->cand[t->choice];
+    }
+    if (!measurable) return t->cand[0];
+    if (t->settle > 0) {
+        --t->settle;
+        return t->cand[0];
+    }
+    if (t->cur < t->n) {
+        const int f = t->cand[t->cur];
+        if (t->issued == 0) t->launch0[t->cur] = c->ring.head;
+        if (++t->issued == t->per) {
+            ++t->cur;
+            t->issued = 0;
+        }
+        return f;
+    }
+    // every candidate has had its turn: are the records in?
+    const long long last = t->launch0[t->n - 1] + t->per - 1;
+    if (c->ring.head > last + 64) {  // (a launch of the trial was never measured -- timed with events, or not ordered: keep the prior)
+        t->choice = 0;
+        t->chain_ref = chain_now;
+        return t->cand[0];
+    }
+    for (int i = 0; i < t->n; ++i)
+        for (int q = 0; q < t->per; ++q)
+            if (*(volatile unsigned long long*)&c->h_span[(t->launch0[i] + q) % kRing] == 0) return t->cand[0];
+    int best = 0;
+    for (int i = 0; i < t->n; ++i) {
+        double ticks;
+        if (in_flight > 1) {
+            const unsigned long long e0 = *(volatile unsigned long long*)&c->h_end[t->launch0[i] % kRing];
+            const unsigned long long e1 = *(volatile unsigned long long*)&c->h_end[(t->launch0[i] + t->per - 2) % kRing];
+            ticks = e1 > e0 ? (double)(e1 - e0) / (double)(t->per - 2) : 1.0e18;
+        } else {
+            ticks = 1.0e18;
+            for (int q = 1; q < t->per; ++q) {
+                const double v = (double)*(volatile unsigned long long*)&c->h_span[(t->launch0[i] + q) % kRing];
+                ticks = v < ticks ? v : ticks;
+            }
+        }
+        t->cost[i] = (float)(ticks * 1.0e-5);  // 100 MHz ticks -> ms
+        // (another kernel must be 2 % faster than the prior's to replace it: the spans of equal kernels differ by about that much)
+        if (i > 0 && t->cost[i] < t->cost[best] * (best == 0 ? 0.98f : 1.0f)) best = i;
+    }
+    t->choice = best;
+    t->chain_ref = chain_now;
+    return t->cand[best];
+}
+
 // Enqueue one launch on `s`: ONE frame with the context's uniforms into `out` (nullptr -> ctx-owned buffer), or, with
 // batch_u / batch_out, n_frames (2 .. kBatchMax) frames of the same scene, each with its own uniforms and output buffer.
 int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, float4* out, hipStream_t s, bool frame_events,
@@ -427,17 +551,25 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // a quarter with two launches in flight counts 3.2 and keeps two lanes: 0.190 / 0.217 per frame)
         fl = (rays_per_lane >= 4.5 || (short_chains && rays_per_lane >= 1.2)) ? 6 : (rays_per_lane >= 2.0 ? 11 : 10);
     }
-    // persistent wavefronts (12; vr_pw.h) exist for launches of one frame
-    if ((fl == 12 || fl == 13 || fl == 16 || fl == 17) && n_frames != 1) fl = 6;
-    // two steps ahead (16, 17; march_p2_kernel): lit / unlit shader, TF slot 0 in LDS, the bricked copy below 4 GiB with rows and
-    // slabs of bricks below 2^24 slots (make_cell_bricked's 24-bit multiplies); else 13 / 12
-    bool p2_ok = (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC) && c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c &&
-                 c->tf[0].res_o + 2 <= 8192 && c->layout_mode == 0 && c->vol_bricked[0] && c->vol_bdens[0] && off32 && n_frames == 1;
+    // persistent wavefronts (12, 13; vr_pw.h) exist for launches of one frame
+    if ((fl == 12 || fl == 13) && n_frames != 1) fl = 6;
+    // two steps ahead (16, 17; march_p2_kernel, vr_p2.h): lit / unlit shader and the three-volume composite (with its brick records:
+    // checked once can_skip is known); TF slot 0 (one resolution for both tables) and the three axis tables in LDS; the bricked copy
+    // with 32-bit slots, rows and slabs of bricks below 2^24 slots; a volume of 4 GiB or more through a moving window of at least
+    // four z-slabs of bricks.  Launches of several frames and launches in flight included.  Else 13 / 12 (one frame) or 6.
+    const int p2_vol = variant == VR_VARIANT_VOLUME_MASK ? 2 : 0;
+    bool p2_ok = (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC || variant == VR_VARIANT_VOLUME_MASK) && c->pw_ltf &&
+                 c->tf[0].res_o == c->tf[0].res_c && c->tf[0].res_o + 2 <= 8192 && c->layout_mode == 0 && c->vol_bricked[p2_vol] && c->vol_bdens[p2_vol];
+    unsigned p2_lds = 0;
     if (p2_ok) {
-        const size_t nbx = ((unsigned)c->vol[0].nx + kVbM) >> kVbS, nby = ((unsigned)c->vol[0].ny + kVbM) >> kVbS, nbz = ((unsigned)c->vol[0].nz + kVbM) >> kVbS;
-        p2_ok = nbx * nby * nbz * kVbN * 16 <= 0xFFFFFFFFull && nbx * nby * kVbN < (1u << 24);
+        const size_t nbx = ((unsigned)c->vol[p2_vol].nx + kVbM) >> kVbS, nby = ((unsigned)c->vol[p2_vol].ny + kVbM) >> kVbS, nbz = ((unsigned)c->vol[p2_vol].nz + kVbM) >> kVbS;
+        const size_t slab = nbx * nby * kVbN, window = variant == VR_VARIANT_BASIC ? 0x3fffffffull : 0x0fffffffull;
+        const size_t lds = (size_t)(c->tf[0].res_o + 2) * 16 + ((size_t)c->vol[p2_vol].nx + c->vol[p2_vol].ny + c->vol[p2_vol].nz + 3) * 8;
+        p2_ok = slab * nbz <= 0xFFFFFFFFull && slab < (1u << 24) && (c->p2_window ? c->p2_window / slab >= 3 : window / slab >= 4) && lds <= 160u * 1024u;
+        p2_lds = (unsigned)lds;
     }
-    if ((fl == 16 || fl == 17) && !p2_ok) fl = fl == 16 ? 13 : 12;
+    if ((fl == 16 || fl == 17) && !p2_ok) fl = n_frames != 1 ? 6 : (fl == 16 ? 13 : 12);
+    if (fl == 16 && variant == VR_VARIANT_VOLUME_MASK) fl = 17;  // (the composite's form is the skipping one: its mask records)
     // LDS tiles (15; vr_lt.h): the lit shader, launches of one frame
     if (fl == 15 && (n_frames != 1 || variant != VR_VARIANT_LIGHT)) fl = 6;
     // mixed lanes per ray (14; vr_mixed.h): launches of one frame, shaders that have a depth-parallel form
@@ -456,6 +588,10 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     if (variant == VR_VARIANT_VOLUME_MASK)  // mask and CT must share one grid so that one brick index serves both
         can_skip = can_skip && c->vol_bricks[0] && c->vol[0].nx == c->vol[2].nx && c->vol[0].ny == c->vol[2].ny &&
                    c->vol[0].nz == c->vol[2].nz;
+    if ((fl == 16 || fl == 17) && variant == VR_VARIANT_VOLUME_MASK && !can_skip) {  // (no brick records: no on-demand mask fetch)
+        fl = n_frames != 1 ? 6 : 12;
+        c->last_flavour = fl;
+    }
     if (can_skip) {
         P.skip_vol = sv;
         P.bnx = (c->vol[sv].nx + kBrickCells - 1) >> kBrickShift;
@@ -524,27 +660,45 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         P.brick_dist = c->brick_dist;
     }
 
-    // Default choice, second part: the persistent kernel (vr_pw.h: TF slot 0 in LDS, 4 wavefronts per SIMD, one launch at a time on
-    // the machine) where it measured faster than the one-lane kernel on whole frames of the bricked layout, one frame at a
-    // time (turntable, ms per frame, gpurun_out/r3k): volumes in which next to nothing can be skipped (noisy air
-    // under the default ramp: 2.95 -> 2.61 with the corner loads pipelined) and rays that hardly terminate (the longest chain
-    // of an earlier launch >= 400 samples -- the thin table: 0.80 -> 0.73).  It loses where most of the frame is skipped (C2
-    // 0.13 -> 0.17, C5 3.33 -> 3.84), on the three-volume composite (0.74 -> 0.78) and with other launches in flight (its
-    // workgroups fill the machine: a second launch waits), and is level within the spread between boxes on C3's default table.
-    if (c->flavour == 0 && c->default_flavour == 0 && c->pw_policy && fl == 6 && n_frames == 1 && off32 && c->frames_in_flight == 1 &&
-        (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC)) {
-        const long long px_all = (long long)tile_count(c, rank, world) * kTile * kTile;
-        const bool whole_frame = (double)px_all / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 4.5;
-        const bool nothing_to_skip = !can_skip || c->active_fraction >= 0.9;
-        // (16 = the no-skip kernel with the corner loads two steps ahead, when TF slot 0 fits LDS and the bricked copy is in
-        // use: noisy air 2.60 -> 2.04 ms; 13 otherwise)
-        if (whole_frame && nothing_to_skip) fl = p2_ok ? 16 : 13;
-        else if (whole_frame && chain_known >= 400u + 1u) fl = 12;
-        // (17 = two steps ahead with the skipping decided ahead of the loads: C3's default table 0.644 -> 0.610 ms; it loses where
-        // the chains are short -- C2, longest chain 102: 0.111 -> 0.161 -- and to 12 where they are longest -- thin: 0.704 / 0.782)
-        else if (whole_frame && p2_ok && can_skip && chain_known >= 200u + 1u) fl = 17;
-        c->last_flavour = fl;
+    // Default choice, second part -- THE PRIOR: what runs before anything has been measured.  Whole frames of the lit / unlit shader
+    // and of the composite, one launch at a time: the kernel with the corner loads two steps ahead (vr_p2.h) -- 17, or 16 where next to
+    // nothing can be skipped (noisy air under the default ramp 2.95 -> 1.97 ms; C3 0.65 -> 0.51; C4 0.72 -> 0.57) -- unless an earlier
+    // launch of this shape says its chains are short (C2, longest chain 102: a packet is too short for the pipeline's fill and a
+    // dequeue, 0.111 -> 0.161).  With launches in flight, several frames per launch and shares of a frame: the first part's choice.
+    const bool p2_variant = variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC || (variant == VR_VARIANT_VOLUME_MASK && can_skip);
+    const long long px_all = (long long)tile_count(c, rank, world) * kTile * kTile;
+    const bool whole_frame = (double)px_all / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 4.5;
+    const bool nothing_to_skip = !can_skip || c->active_fraction >= 0.9;
+    const bool auto_choice = c->flavour == 0 && c->default_flavour == 0;
+    if (auto_choice && c->pw_policy && fl == 6 && n_frames == 1 && c->frames_in_flight == 1 && whole_frame && p2_ok && p2_variant) {
+        const bool short_chains = chain_known != 0 && chain_known - 1 < 128;
+        if (nothing_to_skip && variant != VR_VARIANT_VOLUME_MASK) fl = 16;
+        else if (!short_chains) fl = 17;
     }
+    // ... and THE MEASURED CHOICE (tune_pick): the eligible forms take turns on the caller's own frames, the fastest by the launches'
+    // own records stays.  Candidates: the prior; the two-steps-ahead kernel; the one-lane kernel; the depth-parallel kernel (launches
+    // that leave the machine part empty) or the persistent kernel without the pipeline (the longest chains).
+    if (auto_choice && c->tune_mode && c->pw_policy) {
+        int cand[4], n = 0;
+        auto add = [&](int f) {
+            for (int i = 0; i < n; ++i)
+                if (cand[i] == f) return;
+            if (n < 4) cand[n++] = f;
+        };
+        add(fl);
+        if (p2_ok && p2_variant) add((nothing_to_skip && variant != VR_VARIANT_VOLUME_MASK) || !can_skip ? 16 : 17);
+        add(6);
+        const bool dp_variant = variant != VR_VARIANT_ILLUSTRATIVE && variant != VR_VARIANT_LIGHT_INSHADER;
+        if (!whole_frame && dp_variant) add((double)px_all * c->frames_in_flight * n_frames / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 2.0 ? 11 : 10);
+        else if (n_frames == 1 && (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC)) add(12);
+        const unsigned long long key = 0x9E3779B97F4A7C15ull * (((unsigned long long)variant << 56) ^ ((unsigned long long)world << 48) ^ ((unsigned long long)rank << 40) ^
+                                                               ((unsigned long long)c->W << 24) ^ ((unsigned long long)c->H << 8) ^ (packed ? 0x80ull : 0ull) ^
+                                                               ((unsigned long long)n_frames << 4) ^ (unsigned long long)c->frames_in_flight) ^
+                                       (c->brick_epoch * 0xD6E8FEB86659FD93ull) ^ (c->tf_epoch << 20) ^ ((unsigned long long)c->arith << 1) ^ (unsigned long long)c->layout_mode ^ 1ull;
+        const bool measurable = c->order_mode == 1 && c->h_span && c->h_end && !c->event_timing;
+        fl = tune_pick(c, key, cand, n, chain_known, measurable);
+    }
+    c->last_flavour = fl;
 
     if (c->layout_mode == 0 && fl != 2 && fl != 3) use_bricked();
     for (int i = 0; i < nvol; ++i)  // (a bricked copy is padded to whole bricks: a volume just below 4 GiB may cross the line)
@@ -621,7 +775,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // older one's buffer may be recycled under this launch; ordered behind it by its event (long complete by then)
         const unsigned long long okey = ((unsigned long long)grid.x << 32) ^ ((unsigned long long)block.x << 20) ^
                                         ((unsigned long long)variant << 16) ^ ((unsigned long long)world << 8) ^ (unsigned long long)rank ^
-                                        ((unsigned long long)fl << 44) ^ (packed ? 1ull << 63 : 0ull);
+                                        ((unsigned long long)(fl == 14 ? 14 : 0) << 44) ^ (packed ? 1ull << 63 : 0ull);
+        // (not the flavour: the kernels that march one packet per wavefront -- 6, 12, 13, 16, 17 -- share the logical blocks, so a
+        // launch order sorted behind one of them serves the others: the measured choice below tries them in turn on a live scene)
         P.order = nullptr;
         const unsigned* mixed_items = nullptr;  // fl 14: the item list of an earlier launch of this shape, once one exists
         unsigned mixed_grid = 0;
@@ -653,6 +809,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const bool time_with_events = !(ordered && c->h_span) || c->event_timing;
         c->ring_events[slot] = time_with_events;
         if (c->h_span) c->h_span[slot] = 0;
+        if (c->h_end) c->h_end[slot] = 0;
         if (time_with_events) VR_HIP(c, hipEventRecord(c->ring.k0[slot], s));
         {
             LaunchDesc L;
@@ -669,8 +826,9 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.pw_pipe = false;
             L.pw_p2 = false;
             L.pw_p2_skip = false;
+            L.pw_p2_win = false;
             L.lds_bytes = 0;
-            L.queue = PwQueue{nullptr, 0u, 0u};
+            L.queue = PwQueue{nullptr, 0u, 0u, 0u, 0u};
             L.mixed_items = nullptr;
             L.n_logical = 0;
             L.grid = grid;
@@ -695,20 +853,31 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 // have one resolution and fit beside nothing else (R <= 8190: 128 KiB)
                 // (march_p2_kernel: two corner buffers, 3 wavefronts per SIMD at most; with every ray sampling all the time two per
                 // SIMD are faster -- the corner data in flight is many times the L1 either way: noisy air 2.13 -> 2.04 ms)
+                const bool p2 = fl == 16 || fl == 17;
                 unsigned pw_threads = fl == 17 ? 768u : (fl == 16 ? 512u : 1024u);
-                if ((fl == 16 || fl == 17) && c->p2_threads) pw_threads = c->p2_threads;  // (VR_EXP_P2_THREADS: 64 .. 768)  // (march_p2_kernel: two corner buffers, 3 wavefronts per SIMD)
+                // (launches in flight: the same shape.  Two workgroups of 6 wavefronts do not share a CU -- the second one's wavefronts
+                // would have to go 1-1-2-2 over the SIMDs where the dispatcher deals 2-2-1-1: measured 0.75 ms per C3 frame, what
+                // one such workgroup per CU takes -- and two of 4 run at 8 wavefronts per CU: 0.63 against 0.54; gpurun_out/r4c)
+                unsigned wg_per_cu = 1;
+                if (p2 && c->p2_threads) pw_threads = c->p2_threads;  // (VR_EXP_P2_THREADS: 64 .. 768)
+                if (p2 && c->p2_wgs) wg_per_cu = c->p2_wgs;           // (VR_EXP_P2_WGS: workgroups per CU the grid is sized for)
                 const unsigned per_wg = pw_threads / 64u;
-                const unsigned wgs = (grid.x + per_wg - 1u) / per_wg;
+                const unsigned items = grid.x * (unsigned)n_frames;
+                const unsigned wgs = (items + per_wg - 1u) / per_wg;
                 L.pw = true;
                 L.pw_pipe = fl == 13;
-                L.pw_p2 = fl == 16 || fl == 17;
+                L.pw_p2 = p2;
                 L.pw_p2_skip = fl == 17 && P.brick_dist != nullptr;
+                L.pw_p2_win = p2 && (!off32 || c->p2_window != 0);
                 L.pw_ltf = c->pw_ltf && c->tf[0].res_o == c->tf[0].res_c && c->tf[0].res_o + 2 <= 8192;
-                L.lds_bytes = L.pw_ltf ? (unsigned)(c->tf[0].res_o + 2) * 16u : 0u;
+                L.lds_bytes = p2 ? p2_lds : (L.pw_ltf ? (unsigned)(c->tf[0].res_o + 2) * 16u : 0u);
                 L.queue.heads = c->d_pw_heads + (size_t)cb * 8 * 64;
                 L.queue.n_items = grid.x;
                 L.queue.steal = c->pw_steal ? 1u : 0u;
-                L.grid = dim3(wgs < (unsigned)c->n_cus ? wgs : (unsigned)c->n_cus);
+                L.queue.p2_window = c->p2_window;
+                L.queue.dynamic = p2 && c->p2_dynq == 1 ? 1u : 0u;
+                const unsigned max_wgs = (unsigned)c->n_cus * wg_per_cu;
+                L.grid = dim3(wgs < max_wgs ? wgs : max_wgs);
                 L.block = dim3(pw_threads);
                 if (c->pw_heads_dirty[cb]) VR_HIP(c, hipMemsetAsync(L.queue.heads, 0, 8 * 64 * sizeof(unsigned), s));
                 c->pw_heads_dirty[cb] = !ordered;  // (an ordered launch's sort clears them behind it)
@@ -749,7 +918,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, c->order_stream, c->d_block_counts[cb], (int)grid.x, o.buf,
                                c->h_chain ? c->h_chain + (c->order_seq % kOrderRing) : (unsigned*)nullptr,
                                (c->h_span && !time_with_events) ? c->h_span + slot : (unsigned long long*)nullptr,
-                               pw ? c->d_pw_heads + (size_t)cb * 8 * 64 : (unsigned*)nullptr);
+                               pw ? c->d_pw_heads + (size_t)cb * 8 * 64 : (unsigned*)nullptr,
+                               (c->h_span && c->h_end && !time_with_events) ? c->h_end + slot : (unsigned long long*)nullptr);
             VR_HIP(c, hipGetLastError());
             o.has_items = false;
 #if VR_EXPERIMENTAL_FLAVOURS
@@ -1048,7 +1218,14 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
         const int t = atoi(e);
         if (t >= 64 && t <= 768 && t % 64 == 0) c->p2_threads = (unsigned)t;
     }
+    if (const char* e = getenv("VR_EXP_P2_WGS")) c->p2_wgs = (unsigned)(atoi(e) > 0 && atoi(e) <= 8 ? atoi(e) : 0);
+    if (const char* e = getenv("VR_EXP_P2_DYNQ")) c->p2_dynq = atoi(e);
+    if (const char* e = getenv("VR_EXP_P2_WINDOW")) {  // records per gather window of march_p2_kernel (tests: the moving window on small volumes)
+        const long long w = atoll(e);
+        if (w > 0 && w <= 0x3fffffffll) c->p2_window = (unsigned)w;
+    }
     if (const char* e = getenv("VR_EXP_PW_POLICY")) c->pw_policy = atoi(e);
+    if (const char* e = getenv("VR_EXP_TUNE")) c->tune_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_XCD")) c->pw_xcd_mode = atoi(e);
     if (!hip_ok(hipMalloc(&c->d_pw_heads, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMalloc(queue heads)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipMemset(c->d_pw_heads, 0, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMemset(queue heads)")) return bail(VR_ERR_HIP);
@@ -1083,6 +1260,10 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     }
     if (const char* e = getenv("VR_EXP_SPLIT_PCT")) c->split_pct = atoi(e) > 0 ? atoi(e) : 75;
     if (const char* e = getenv("VR_EXP_SPLIT_MIN")) c->split_min = atoi(e) > 0 ? atoi(e) : 64;
+    if (hipHostMalloc((void**)&c->h_end, kRing * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess)
+        std::memset(c->h_end, 0, kRing * sizeof(unsigned long long));
+    else
+        c->h_end = nullptr;  // (no measured kernel choice with launches in flight: the prior's pick stays)
     if (hipHostMalloc((void**)&c->h_chain, kOrderRing * sizeof(unsigned), hipHostMallocDefault) == hipSuccess)
         std::memset(c->h_chain, 0, kOrderRing * sizeof(unsigned));
     else
@@ -1156,6 +1337,7 @@ void vr_destroy(vr_ctx* c)
     if (c->h_items) (void)hipHostFree(c->h_items);
     if (c->h_chain) (void)hipHostFree(c->h_chain);
     if (c->h_span) (void)hipHostFree(c->h_span);
+    if (c->h_end) (void)hipHostFree(c->h_end);
     for (int k = 0; k < c->n_flight; ++k) (void)hipStreamDestroy(c->flight[k]);
     if (c->tm.ev_begin) (void)hipEventDestroy(c->tm.ev_begin);
     if (c->tm.ev_k0) (void)hipEventDestroy(c->tm.ev_k0);
@@ -1216,6 +1398,7 @@ static int tf_upload_one(vr_ctx* c, int slot, const float* table, uint32_t R, bo
     if (R == 0 || R > (1u << 24)) return fail(c, VR_ERR_INVALID_ARG, "vr_tf_upload: bad resolution");
     VR_HIP(c, hipSetDevice(c->device));
     VR_HIP(c, hipDeviceSynchronize());  // asynchronous renders on the caller's streams may still read the table
+    ++c->tf_epoch;
     if (is_color) {
         if (c->tf[slot].res_c != (int)R) {
             if (c->tf_color[slot]) (void)hipFree(c->tf_color[slot]);
@@ -1669,6 +1852,21 @@ int vr_volume_layout(vr_ctx* c, int slot, int* flags)
     *flags = (c->vol_dens[slot] ? 1 : 0) | (c->vol_grad_derived[slot] ? 2 : 0) | (c->last_otf ? 4 : 0) |
              ((c->vol_bricked[slot] && c->layout_mode == 0) ? 8 : 0);
     return VR_OK;
+}
+
+int vr_kernel_choice(vr_ctx* c, int flavours[4], float ms_per_launch[4], int* chosen)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    const vr_ctx::Tune* t = nullptr;
+    for (const auto& e : c->tune)
+        if (e.key != 0 && e.used != 0 && (!t || e.used > t->used)) t = &e;
+    if (chosen) *chosen = t ? t->choice : -1;
+    if (!t) return 0;
+    for (int i = 0; i < 4; ++i) {
+        if (flavours) flavours[i] = i < t->n ? t->cand[i] : 0;
+        if (ms_per_launch) ms_per_launch[i] = i < t->n ? t->cost[i] : 0.0f;
+    }
+    return t->n;
 }
 
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)

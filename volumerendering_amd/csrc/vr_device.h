@@ -130,6 +130,8 @@ struct PwQueue {
     unsigned* heads;
     unsigned n_items;  // logical blocks of the launch (a multiple of 8)
     unsigned steal;    // 1: a wavefront whose class is exhausted takes items of the other classes
+    unsigned dynamic;    // march_p2_kernel: 1 = a wavefront's first item comes from the heads as well (no static deal)
+    unsigned p2_window;  // march_p2_kernel<.., WIN>: records per gather window when not 0 (tests: a small window on a small volume)
 };
 
 // What enqueue_render decided about one march launch; handed to launch_march of the arithmetic mode's translation unit
@@ -148,6 +150,7 @@ struct LaunchDesc {
     bool pw_pipe;     // ... with the next step's corner loads software-pipelined (lit / unlit shader)
     bool pw_p2;       // ... the no-skip form with the corner loads two steps ahead (march_p2_kernel; TF slot 0 in LDS, bricked copy)
     bool pw_p2_skip;  // ... ... with skipping by whole wavefronts (march_p2_kernel<V, true>)
+    bool pw_p2_win;   // ... ... a bound volume of 4 GiB or more: the gather window moves (march_p2_kernel<.., WIN>)
     unsigned lds_bytes;
     PwQueue queue;
     const unsigned* mixed_items;  // lanes per ray chosen per packet (vr_mixed.h): the item list, grid = its positions

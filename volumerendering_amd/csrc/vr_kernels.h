@@ -944,11 +944,14 @@ __device__ __forceinline__ bool opacity_is_zero(const MarchParams& P, float d)
 // The lit shader from the interpolated voxel to the blend (BasicVolLightApp.wgsl:216-223), on (x, y) / (r, g) register pairs
 // so that the packed instructions need no shuffling; per component the operations and their order are those of
 // normalize3 / shade / blend.  zw = (gradient z, density), gxy = (gradient x, gradient y), tq = the table texels of `density`.
-template <bool UNI = false>
-__device__ __forceinline__ void light_shade_blend(const MarchParams& P, f3 w, v2f zw, v2f gxy, const TfFetch& tq, float4& dst)
+// (lpos / dif / amb, kD / kA: the scene's light -- the uniforms of BasicVolLightApp, the constants of VolumeMaskApp.wgsl:116-123;
+// MASKED: a lane whose mask sample says so takes the dose table's sample `trt` unshaded instead, VolumeMaskApp.wgsl:201-205)
+template <bool UNI = false, bool MASKED = false>
+__device__ __forceinline__ void shade_blend_packed(f3 lpos, f3 dif, f3 amb, float kD, float kA, f3 w, v2f zw, v2f gxy, const TfFetch& tq, float4& dst,
+                                                   bool masked = false, f3 trt_rgb = f3{0.0f, 0.0f, 0.0f}, float trt_a = 0.0f)
 {
-    v2f Lxy = v2f{P.light_pos[0] - w.x, P.light_pos[1] - w.y};
-    float Lz = P.light_pos[2] - w.z;
+    v2f Lxy = v2f{lpos.x - w.x, lpos.y - w.y};
+    float Lz = lpos.z - w.z;
 #if VR_FUSED
     const v2f inv = inv_sqrt_exact2<UNI>(mad(zw.x, zw.x, mad(gxy.y, gxy.y, gxy.x * gxy.x)), mad(Lz, Lz, mad(Lxy.y, Lxy.y, Lxy.x * Lxy.x)));
 #else
@@ -966,19 +969,32 @@ __device__ __forceinline__ void light_shade_blend(const MarchParams& P, f3 w, v2
     const v2f nl = Nxy * Lxy;
     const float m = max0((nl.x + nl.y) + Nz * Lz);
 #endif
-    const v2f sh_rg = mad2(v2f{P.light_dif[0], P.light_dif[1]} * m, v2f{2.5f, 2.5f}, v2f{P.light_amb[0], P.light_amb[1]} * 0.5f);
-    const float sh_b = mad(P.light_dif[2] * m, 2.5f, P.light_amb[2] * 0.5f);
-    const float opacity = lerpf(tq.o0, tq.o1, tq.fo);
+    const v2f sh_rg = mad2(v2f{dif.x, dif.y} * m, v2f{kD, kD}, v2f{amb.x, amb.y} * kA);
+    const float sh_b = mad(dif.z * m, kD, amb.z * kA);
+    float opacity = lerpf(tq.o0, tq.o1, tq.fo);
     const v2f c_rg = lerp2(v2f{tq.c0.x, tq.c0.y}, v2f{tq.c1.x, tq.c1.y}, tq.fc);
     const float c_b = lerpf(tq.c0.z, tq.c1.z, tq.fc);
-    const v2f src_rg = (c_rg * sh_rg) * opacity;  // FrontToBackBlend: (rgb * a, a)
-    const float src_b = (c_b * sh_b) * opacity;
+    v2f rgb_rg = c_rg * sh_rg;
+    float rgb_b = c_b * sh_b;
+    if constexpr (MASKED) {
+        rgb_rg = masked ? v2f{trt_rgb.x, trt_rgb.y} : rgb_rg;
+        rgb_b = masked ? trt_rgb.z : rgb_b;
+        opacity = masked ? trt_a : opacity;
+    }
+    const v2f src_rg = rgb_rg * opacity;  // FrontToBackBlend: (rgb * a, a)
+    const float src_b = rgb_b * opacity;
     const float om = 1.0f - dst.w;
     const v2f d_rg = mad2(src_rg, v2f{om, om}, v2f{dst.x, dst.y});
     dst.x = d_rg.x;
     dst.y = d_rg.y;
     dst.z = mad(om, src_b, dst.z);
     dst.w = mad(om, opacity, dst.w);
+}
+template <bool UNI = false>
+__device__ __forceinline__ void light_shade_blend(const MarchParams& P, f3 w, v2f zw, v2f gxy, const TfFetch& tq, float4& dst)
+{
+    shade_blend_packed<UNI>(mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]), mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
+                            mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]), 2.5f, 0.5f, w, zw, gxy, tq, dst);
 }
 
 // ZSKIP (the host has verified what exact empty-space skipping needs: finite colour table and light, SKIP kernels only):
@@ -1761,7 +1777,8 @@ constexpr int kOrderMaxBlocks = 192 * 1024;  // launches with more blocks keep t
 __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long long* __restrict__ in, int n_blocks,
                                                             unsigned* __restrict__ order, unsigned* __restrict__ longest_chain,
                                                             unsigned long long* __restrict__ span_ticks,
-                                                            unsigned* __restrict__ pw_heads)
+                                                            unsigned* __restrict__ pw_heads,
+                                                            unsigned long long* __restrict__ end_tick = nullptr)
 {
     if (pw_heads != nullptr && threadIdx.x < 8) pw_heads[threadIdx.x * 64] = 0u;
     __shared__ unsigned hist[1024];  // [class 0..7][bucket 0..127]
@@ -1831,7 +1848,11 @@ __global__ __launch_bounds__(1024) void order_blocks_kernel(const unsigned long 
         atomicMin(&t_first, my_first);
         atomicMax(&t_last, my_last);
         __syncthreads();
-        if (t == 0) *span_ticks = t_last >= t_first ? t_last - t_first + 1ull : 1ull;  // (0 = not written yet)
+        if (t == 0) {
+            if (end_tick) *end_tick = t_last | 1ull;  // (the last workgroup's end on the device clock; before the span: the host reads the span first)
+            __threadfence_system();
+            *span_ticks = t_last >= t_first ? t_last - t_first + 1ull : 1ull;  // (0 = not written yet)
+        }
     }
     // scatter with one cursor per (class, bucket): the i-th block of class x goes to position 8 * i + x
     for (int k = 0; k * 1024 < n_blocks; ++k) {

@@ -7,6 +7,7 @@
 #include "vr_kernels.h"
 #include "vr_dp.h"
 #include "vr_pw.h"
+#include "vr_p2.h"
 // Kernel forms that lost every A/B -- flavours 2 / 3 (register-staged LDS wave tiles), 4
 // (closed-form leaping), 5 (skipping without runs), 9 (one lane per ray, pipelined corner loads), 14 (lanes per ray chosen per
 // packet), 15 (LDS tiles by LDS-DMA) and layout 2 (gradients on the fly) -- are compiled only with -DVR_EXPERIMENTAL_FLAVOURS=1
@@ -121,11 +122,12 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         else VR_LAUNCH_PW(O, S, false, false);                                                                         \
     } while (0)
     constexpr bool kCanPipe = (V == V_BASIC || V == V_LIGHT);
-    if constexpr (kCanPipe) {
-        if (L.pw_p2) {  // two steps ahead (the host: TF slot 0 in LDS, bricked copy below 4 GiB); skipping by whole wavefronts
-#define VR_LAUNCH_P2(S)                                                                                                \
+    constexpr bool kCanP2 = kCanPipe || V == V_VOLUME_MASK;
+    if constexpr (kCanP2) {
+        if (L.pw_p2) {  // two steps ahead (vr_p2.h; the host: TF slot 0 and the axis tables fit LDS, the bricked copy is in use)
+#define VR_LAUNCH_P2(S, WN, BT)                                                                                        \
     do {                                                                                                               \
-        auto k = march_p2_kernel<V, S>;                                                                                \
+        auto k = march_p2_kernel<V, S, WN, BT>;                                                                        \
         if (L.lds_bytes > 48u * 1024u) {                                                                               \
             static unsigned raised = 0;                                                                                \
             if (L.lds_bytes > raised) {                                                                                \
@@ -136,8 +138,23 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         }                                                                                                              \
         hipLaunchKernelGGL(k, L.grid, L.block, L.lds_bytes, s, B, L.queue);                                            \
     } while (0)
-            if (skip && L.pw_p2_skip) VR_LAUNCH_P2(true);
-            else VR_LAUNCH_P2(false);
+#define VR_LAUNCH_P2_W(S)                                                                                              \
+    do {                                                                                                               \
+        if (L.pw_p2_win) {                                                                                             \
+            if (B.n_frames > 1) VR_LAUNCH_P2(S, true, true);                                                           \
+            else VR_LAUNCH_P2(S, true, false);                                                                         \
+        } else {                                                                                                       \
+            if (B.n_frames > 1) VR_LAUNCH_P2(S, false, true);                                                          \
+            else VR_LAUNCH_P2(S, false, false);                                                                        \
+        }                                                                                                              \
+    } while (0)
+            if constexpr (V == V_VOLUME_MASK) {
+                VR_LAUNCH_P2_W(true);  // (the host asks for it only with the brick records in place)
+            } else {
+                if (skip && L.pw_p2_skip) VR_LAUNCH_P2_W(true);
+                else VR_LAUNCH_P2_W(false);
+            }
+#undef VR_LAUNCH_P2_W
 #undef VR_LAUNCH_P2
             return;
         }
