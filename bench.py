@@ -71,8 +71,8 @@ KERNEL_OF_FLAVOUR = {1: "march_kernel (no skipping)", 2: "march_wtb_light_kernel
                      10: "march_dp_kernel (4 lanes per ray, pipelined)", 11: "march_dp_kernel (2 lanes per ray, pipelined)",
                      12: "march_pw_kernel (persistent wavefronts, TF slot 0 in LDS)",
                      13: "march_pw_kernel (persistent wavefronts, TF slot 0 in LDS, corner loads pipelined)",
-                     16: "march_p2_kernel (persistent wavefronts, corner loads two steps ahead, no skipping)",
-                     17: "march_p2_kernel (persistent wavefronts, corner loads two steps ahead, skipping decided ahead of the loads)"}
+                     16: "march_p2_kernel (persistent wavefronts, indexed corner loads two steps ahead, slot tables in LDS, no skipping)",
+                     17: "march_p2_kernel (persistent wavefronts, indexed corner loads two steps ahead, slot tables in LDS, skipping decided ahead of the loads)"}
 
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"],
@@ -383,8 +383,8 @@ def main():
     ap.add_argument("--turn-frames", type=int, default=628,
                     help="frames of the full-turn leg (one frame at a time, yaw + 0.01 rad per frame: 628 = 2 pi; 0 = skip)")
     ap.add_argument("--settle", type=int, default=24,
-                    help="untimed frames in front of every leg's warm-up: the context measures its candidate kernels on live frames "
-                         "(vr.h, flavour 0) and the leg then times the steady state")
+                    help="untimed LAUNCHES in front of every leg's warm-up (twice as many with launches in flight): the context measures its "
+                         "candidate kernels on live frames (vr.h, flavour 0) and the leg then times the steady state")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-identical", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -519,6 +519,7 @@ def main():
     ctx.set_uniforms(u0)
     sync_all()
 
+    last_choice = {}
     last_batch = {}  # (buffer set, frame of the launch) -> g of the camera the batched leg rendered into it last
     last_single = {}  # buffer set -> g, one frame per launch
 
@@ -589,7 +590,7 @@ def main():
         if mg is not None:
             mg.set_frames_in_flight(1 if nbuf == 1 else 0)
         if args.settle > 0:  # (untimed, and in front of the W warm-up frames: the leg itself is W + K frames from camera 0)
-            run_frames(0, args.settle, nbuf, fpl, present)
+            run_frames(0, args.settle * fpl * (1 if nbuf == 1 else 2), nbuf, fpl, present)  # (counted in LAUNCHES: 2 x with launches in flight)
             sync_all()
         g = run_frames(0, n_warm, nbuf, fpl, present)
         sync_all()
@@ -604,16 +605,20 @@ def main():
             run_frames(g1, min_events - n_steps, nbuf, fpl, present)
             sync_all()
         kt = ctx.kernel_times(min(max(n_steps, min_events), 256))
+        cands, cms, chosen = ctx.kernel_choice()  # what the default's measured choice knows of this leg's launch shape
+        last_choice.clear()
+        last_choice.update({"candidates": cands, "ms_per_launch": [round(x, 4) for x in cms], "kept": cands[chosen] if chosen >= 0 else None,
+                            "ran_last": ctx.last_kernel_flavour()})
         if dist is not None:  # MAX over ranks
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, kt, comp, fetched
+        return dt, kt, comp, fetched, dict(last_choice)
 
     def leg(res, nbuf, steps):
-        dt, kt, comp, fetched = res
+        dt, kt, comp, fetched = res[:4]
         ms = dt / steps * 1e3
-        return {"launches_in_flight": nbuf, "ms_per_step": round(ms, 4), "fps": round(1e3 / ms, 2),
+        return {"launches_in_flight": nbuf, "kernel_choice": res[4] if len(res) > 4 else None, "ms_per_step": round(ms, 4), "fps": round(1e3 / ms, 2),
                 "value": round(comp / dt / 1e9, 3), "fetched_gsamples_per_s": round(fetched / dt / 1e9, 3),
                 "composited_samples_timed": comp,
                 "kernel_ms_median": round(float(np.median(kt)), 4) if len(kt) else None,
@@ -628,7 +633,7 @@ def main():
     # measured the contract's way: HIP events on the launch stream around each of 20 more one-at-a-time frames, outside the
     # timed regions.
     ctx.set_kernel_timing(True)
-    _, kt_events, _, _ = timed_leg(1, 3, 20)
+    _, kt_events, _, _, _ = timed_leg(1, 3, 20)
     ctx.set_kernel_timing(False)
     res_present = timed_leg(1, args.warmup, args.steps, present=True) if not multi else None
     nbuf_over = max_flight if mg is not None else min(args.in_flight, max_flight)
@@ -783,11 +788,15 @@ def main():
 
     # ---- roofline: measured fabric bytes (rocprofv3 PMC passes on the same turntable, launched from here) ---------------
     pmc, pmc_note, pmc_same = {}, "skipped", {}
+    # (the counter passes profile a handful of launches of a fresh process: they are told which kernel the serial leg's measured
+    # choice kept, so that what is profiled is what was timed and not the first candidates of a new trial)
+    pargs = argparse.Namespace(**vars(args))
+    pargs.flavour = args.flavour or ran
     if rank == 0 and world == 1 and not multi and not args.no_live_pmc:
         t0 = time.time()
-        pmc, pmc_note = live_pmc(args, PMC_PASSES + (PMC_EXTRA if args.pmc_extra else []), identical=args.identical_frames)
+        pmc, pmc_note = live_pmc(pargs, PMC_PASSES + (PMC_EXTRA if args.pmc_extra else []), identical=args.identical_frames)
         if not args.identical_frames:  # the same frames four times over: what the caches make of identical uniforms
-            pmc_same, _ = live_pmc(args, [["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"],
+            pmc_same, _ = live_pmc(pargs, [["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"],
                                           ["TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"]], identical=True)
         log(f"[bench] rocprofv3 counter passes: {time.time() - t0:.1f}s {pmc_note}")
     traffic = None
@@ -855,7 +864,9 @@ def main():
         # the same two units measured on launches of `fpl` frames (one launch at a time: counters of overlapping dispatches
         # cannot be told apart), instead of scaled from the one-frame launches
         if fpl > 1 and not args.no_live_pmc:
-            bp, bnote = live_pmc(args, [["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"], ["GRBM_GUI_ACTIVE", "TA_BUSY_avr"]], frames_per_launch=fpl,
+            bargs = argparse.Namespace(**vars(args))
+            bargs.flavour = args.flavour or (over.get("kernel_choice") or {}).get("kept") or 0
+            bp, bnote = live_pmc(bargs, [["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"], ["GRBM_GUI_ACTIVE", "TA_BUSY_avr"]], frames_per_launch=fpl,
                                  identical=args.identical_frames)
             if "SQ_ACTIVE_INST_VALU" in bp and "GRBM_GUI_ACTIVE" in bp:
                 bcyc = bp["GRBM_GUI_ACTIVE"] / 8.0

@@ -255,6 +255,13 @@ int vr_present_async(vr_ctx* ctx, const void* d_frame, void* d_bgra8, void* stre
  * same output merge (App/src/renderer/PipelineBuilder.cpp:142-154); bit-identical to vr_unpack_tiles_async + vr_present_async. */
 int vr_present_tiles_async(vr_ctx* ctx, const void* d_gathered, int world, int rank_stride_tiles, void* d_bgra8, void* stream);
 
+/* Presenting where the tiles are rendered (multi-GPU, the presented frame alone is wanted): vr_present_packed_async applies the same
+ * output merge to a rank's PACKED tiles (n_tiles x 64 x 64 RGBA32F -> as many BGRA8Unorm words, same order) -- the gather then moves
+ * 4 bytes per pixel instead of 16 -- and vr_unpack_tiles_bgra8_async is vr_unpack_tiles_strided_async for such gathered BGRA8 tiles
+ * (gathered[r][n][64*64] words -> the W x H frame).  Pixel for pixel the bytes of vr_present_async on the assembled frame.     */
+int vr_present_packed_async(vr_ctx* ctx, const void* d_tiles_rgba, int n_tiles, void* d_tiles_bgra8, void* stream);
+int vr_unpack_tiles_bgra8_async(vr_ctx* ctx, const void* d_gathered_bgra8, int world, int rank_stride_tiles, void* d_bgra8, void* stream);
+
 /* Packed tiles of the last vr_render_tiles (host copy). */
 int vr_download_tiles(vr_ctx* ctx, float* tiles_rgba, uint64_t* composited_samples);
 

@@ -107,9 +107,14 @@ int vr_mgpu_device(const vr_mgpu* m, int local_rank);
  *   VR_MGPU_OUT_FRAME    the assembled W x H float frames (vr_unpack_tiles_strided_async: one un-permute pass per frame,
  *                        16 B read + 16 B written per pixel) -- vr_mgpu_frame_device_ptr / vr_mgpu_download
  *   VR_MGPU_OUT_PRESENT  the presented BGRA8Unorm frames (the output merge of App/src/renderer/PipelineBuilder.cpp:142-154
- *                        over the white background), written by vr_present_tiles_async straight from the tile-major
- *                        segments: a viewer that only shows the frame needs no un-permuted float frame at all --
- *                        vr_mgpu_present_device_ptr / vr_mgpu_download_present
+ *                        over the white background) -- vr_mgpu_present_device_ptr / vr_mgpu_download_present.  ALONE (a viewer
+ *                        that only shows the frame): every rank presents its own tiles where it rendered them
+ *                        (vr_present_packed_async; the merge is per pixel, so the bytes are those of presenting the assembled
+ *                        frame), the gather moves BGRA8 words -- 4 bytes per pixel over xGMI instead of 16: 8.3 MB instead of
+ *                        33 MB per 4K frame onto the root -- and the root un-permutes them (vr_unpack_tiles_bgra8_async).
+ *                        VR_MGPU_GATHER_FLOAT=1 in the environment restores the float gather for A/B.  Together with
+ *                        VR_MGPU_OUT_FRAME: float tiles are gathered and the root presents straight from the tile-major
+ *                        segments (vr_present_tiles_async).
  * Both bits may be set.  Takes effect with the next launch; same value on every rank.                              */
 #define VR_MGPU_OUT_FRAME 1
 #define VR_MGPU_OUT_PRESENT 2

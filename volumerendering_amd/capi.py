@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "vr_last_timing", "vr_kernel_times", "vr_reset_kernel_times", "vr_frame_device_ptr", "vr_last_covered_pixels", "vr_last_counters", "vr_set_kernel_flavour", "vr_last_block_trace", "vr_last_kernel_flavour",
     "vr_set_volume_layout", "vr_volume_layout", "vr_viewport", "vr_set_arithmetic", "vr_present_async", "vr_stream", "vr_hint_frames_in_flight",
     "vr_set_kernel_timing", "vr_present_tiles_async", "vr_last_split_packets", "vr_experimental_flavours", "vr_kernel_choice",
+    "vr_present_packed_async", "vr_unpack_tiles_bgra8_async",
 ]
 
 
@@ -124,6 +125,8 @@ def load() -> C.CDLL:
     lib.vr_present_async.argtypes = [vp, vp, vp, vp]
     lib.vr_present_tiles_async.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.vr_hint_frames_in_flight.argtypes = [vp, i32]
+    lib.vr_present_packed_async.argtypes = [vp, vp, C.c_int, vp, vp]
+    lib.vr_unpack_tiles_bgra8_async.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.vr_kernel_choice.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.vr_stream.argtypes = [vp, i32]
     lib.vr_stream.restype = vp

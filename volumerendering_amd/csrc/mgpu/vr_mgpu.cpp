@@ -35,6 +35,8 @@ struct Rank {
     float* gathered[kSlots] = {};  // root: world x batch_cap segments
     float* frame[kSlots] = {};     // root: batch_cap assembled W x H frames, back to back
     uint32_t* present[kSlots] = {};  // root, VR_MGPU_OUT_PRESENT: batch_cap presented BGRA8 frames, back to back
+    uint32_t* ptiles[kSlots] = {};   // this rank's tiles presented where they were rendered (VR_MGPU_OUT_PRESENT alone: 4 B per pixel to gather)
+    uint32_t* pgathered[kSlots] = {};  // root: world x batch_cap such segments
     // stage timeline (vr_mgpu_set_stage_timing): render start, render done, segments gathered, output written
     hipEvent_t tm_t0[kSlots] = {}, tm_r[kSlots] = {}, tm_g[kSlots] = {}, tm_d[kSlots] = {};
     bool tm_valid[kSlots] = {};
@@ -54,10 +56,13 @@ struct vr_mgpu {
     int exp_share = 1;      // experiment (VR_MGPU_EXP_SHARE=N, world of one only): render and gather only rank 0's share of an
                             // N-rank partition -- the timeline of one rank of an N-GPU run on a one-GPU box; frames are incomplete
     int output = VR_MGPU_OUT_FRAME;  // what the root produces from the gathered segments (vr_mgpu_set_output)
+    bool gather_presented = true;    // VR_MGPU_OUT_PRESENT alone: every rank presents its own tiles, BGRA8 tiles are gathered (4 B per
+                                     // pixel over xGMI instead of 16); VR_MGPU_GATHER_FLOAT=1: float tiles, presented on the root (A/B)
     bool stage_timing = false;       // timing events around the three stages of every launch (vr_mgpu_set_stage_timing)
     bool failed = false;             // a collective or an allocation failed half-way: the ranks' queues no longer match up,
                                      // every later call returns the stored error
     unsigned long long frame_no = 0;
+    unsigned long long enqueued = 0;   // device work items enqueued so far (a failed call that enqueued none leaves the ranks in step)
     std::string err, backend;
 };
 
@@ -102,13 +107,19 @@ int alloc_buffers(vr_mgpu* m, Rank& k)
         if (k.gathered[b]) (void)hipFree(k.gathered[b]);
         if (k.frame[b]) (void)hipFree(k.frame[b]);
         if (k.present[b]) (void)hipFree(k.present[b]);
+        if (k.ptiles[b]) (void)hipFree(k.ptiles[b]);
+        if (k.pgathered[b]) (void)hipFree(k.pgathered[b]);
         k.tiles[b] = k.gathered[b] = k.frame[b] = nullptr;
-        k.present[b] = nullptr;
+        k.present[b] = k.ptiles[b] = k.pgathered[b] = nullptr;
         k.used[b] = false;
         k.tm_valid[b] = false;
         MG_HIP(m, hipMalloc(&k.tiles[b], seg * sizeof(float)));
         MG_HIP(m, hipMemset(k.tiles[b], 0, seg * sizeof(float)));
+        MG_HIP(m, hipMalloc(&k.ptiles[b], seg));  // (one BGRA8 word per pixel = a quarter of the float segment's bytes)
+        MG_HIP(m, hipMemset(k.ptiles[b], 0, seg));
         if (k.rank == 0) {
+            MG_HIP(m, hipMalloc(&k.pgathered[b], seg * (size_t)gather_world));
+            MG_HIP(m, hipMemset(k.pgathered[b], 0, seg * (size_t)gather_world));
             MG_HIP(m, hipMalloc(&k.gathered[b], seg * (size_t)gather_world * sizeof(float)));
             MG_HIP(m, hipMemset(k.gathered[b], 0, seg * (size_t)gather_world * sizeof(float)));
             MG_HIP(m, hipMalloc(&k.frame[b], frame_floats * sizeof(float)));
@@ -145,6 +156,8 @@ int setup_rank(vr_mgpu* m, Rank& k)
     }
     MG_HIP(m, hipMalloc(&k.d_red, 4 * sizeof(unsigned long long)));
     MG_HIP(m, hipDeviceSynchronize());
+    // the loop keeps `slots` launches in flight per rank: the context's kernel choice is made for that
+    (void)vr_hint_frames_in_flight(k.ctx, m->one_stream ? 1 : (m->slots > 4 ? 4 : m->slots));
     return VR_OK;
 }
 
@@ -154,6 +167,7 @@ void read_knobs(vr_mgpu* m)
         const int v = atoi(e);
         if (v >= 1 && v <= kSlots) m->slots = v;
     }
+    if (const char* e = getenv("VR_MGPU_GATHER_FLOAT")) m->gather_presented = atoi(e) == 0;
     if (const char* e = getenv("VR_MGPU_EXP_SHARE")) {
         const int v = atoi(e);
         if (v > 1 && m->world == 1) m->exp_share = v;
@@ -276,6 +290,8 @@ void vr_mgpu_destroy(vr_mgpu* m)
             for (hipEvent_t e : {k.tm_t0[b], k.tm_r[b], k.tm_g[b], k.tm_d[b]})
                 if (e) (void)hipEventDestroy(e);
             if (k.present[b]) (void)hipFree(k.present[b]);
+            if (k.ptiles[b]) (void)hipFree(k.ptiles[b]);
+            if (k.pgathered[b]) (void)hipFree(k.pgathered[b]);
             if (k.tiles[b]) (void)hipFree(k.tiles[b]);
             if (k.gathered[b]) (void)hipFree(k.gathered[b]);
             if (k.frame[b]) (void)hipFree(k.frame[b]);
@@ -303,8 +319,10 @@ static int enqueue_frames_impl(vr_mgpu* m, int variant, int n_frames, const vr_u
     const int b = (int)(m->frame_no % (unsigned long long)m->slots);
     const int part_world = m->exp_share > 1 ? m->exp_share : m->world;
     const size_t seg = m->seg_floats ? m->seg_floats : 4;
+    const int tpr = (int)(seg / ((size_t)kTilePx * kTilePx * 4));
+    const bool presented = m->output == VR_MGPU_OUT_PRESENT && m->gather_presented && tpr > 0;
     for (auto& k : m->r)
-        if (!k.tiles[b] || (k.rank == 0 && (!k.gathered[b] || !k.frame[b] || !k.present[b])))
+        if (!k.tiles[b] || !k.ptiles[b] || (k.rank == 0 && !k.pgathered[b]) || (k.rank == 0 && (!k.gathered[b] || !k.frame[b] || !k.present[b])))
             return fail(m, VR_ERR_NOT_READY, "vr_mgpu: buffer set not allocated (an earlier allocation failed)");
     // 1. every local rank renders its tiles into buffer set b, behind the gather that last read that tile buffer (not behind
     //    the output pass that followed it: that one reads the gather buffer and writes the frames, which only the
@@ -323,6 +341,10 @@ static int enqueue_frames_impl(vr_mgpu* m, int variant, int n_frames, const vr_u
         } else {
             MG_VR(m, k, vr_render_tiles_async(k.ctx, variant, k.rank, part_world, k.tiles[b], s_render));
         }
+        ++m->enqueued;
+        // the presented frame alone is wanted: the output merge runs here, on the rank's own tiles (elementwise: the same bytes as
+        // presenting the assembled frame), and the gather below moves BGRA8 words
+        if (presented) MG_VR(m, k, vr_present_packed_async(k.ctx, k.tiles[b], n_frames * tpr, k.ptiles[b], s_render));
         if (m->stage_timing) MG_HIP(m, hipEventRecord(k.tm_r[b], s_render));
         if (!m->one_stream) {
             MG_HIP(m, hipEventRecord(k.ev_render[b], s_render));
@@ -337,7 +359,10 @@ static int enqueue_frames_impl(vr_mgpu* m, int variant, int n_frames, const vr_u
     }
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
-        MG_NCCL(m, ncclGather(k.tiles[b], k.rank == 0 ? k.gathered[b] : nullptr, seg * (size_t)n_frames, ncclFloat, 0, k.comm, k.s_comm));
+        if (presented)
+            MG_NCCL(m, ncclGather(k.ptiles[b], k.rank == 0 ? k.pgathered[b] : nullptr, seg / 4 * (size_t)n_frames, ncclUint32, 0, k.comm, k.s_comm));
+        else
+            MG_NCCL(m, ncclGather(k.tiles[b], k.rank == 0 ? k.gathered[b] : nullptr, seg * (size_t)n_frames, ncclFloat, 0, k.comm, k.s_comm));
     }
     if (m->r.size() > 1) {
         group_open = false;
@@ -351,11 +376,15 @@ static int enqueue_frames_impl(vr_mgpu* m, int variant, int n_frames, const vr_u
     // 3. the root turns the segments into what its consumer reads: the assembled float frames (un-permute: 16 B read + 16 B
     //    written per pixel) and / or the presented BGRA8 frames straight from the tile-major segments (16 + 4 B per pixel,
     //    the output merge of App/src/renderer/PipelineBuilder.cpp:142-154 reading through the permutation)
-    const int tpr = (int)(seg / ((size_t)kTilePx * kTilePx * 4));
     for (auto& k : m->r) {
         MG_HIP(m, hipSetDevice(k.device));
         if (k.rank == 0)
             for (int f = 0; f < n_frames; ++f) {
+                if (presented) {
+                    MG_VR(m, k, vr_unpack_tiles_bgra8_async(k.ctx, k.pgathered[b] + (size_t)f * (seg / 4), part_world, n_frames * tpr,
+                                                            k.present[b] + (size_t)f * m->W * m->H, k.s_comm));
+                    continue;
+                }
                 if (m->output & VR_MGPU_OUT_FRAME)
                     MG_VR(m, k, vr_unpack_tiles_strided_async(k.ctx, k.gathered[b] + (size_t)f * seg, part_world, n_frames * tpr,
                                                               k.frame[b] + (size_t)f * m->W * m->H * 4, k.s_comm));
@@ -377,10 +406,12 @@ static int enqueue_frames(vr_mgpu* m, int variant, int n_frames, const vr_unifor
 {
     if (m->failed) return VR_ERR_HIP;  // (m->err still holds what went wrong)
     bool group_open = false;
+    const unsigned long long before = m->enqueued;
     const int rc = enqueue_frames_impl(m, variant, n_frames, uniforms, group_open);
     if (rc < 0) {
         if (group_open) (void)ncclGroupEnd();
-        if (rc != VR_ERR_NOT_READY || group_open) m->failed = true;
+        // (an argument error on the first rank, before anything was enqueued, leaves every queue as it was: the handle stays usable)
+        if (m->enqueued != before || group_open) m->failed = true;
     }
     return rc;
 }
@@ -550,6 +581,7 @@ int vr_mgpu_set_frames_in_flight(vr_mgpu* m, int frames)
     int rc = vr_mgpu_wait(m);
     if (rc != VR_OK) return rc;
     m->one_stream = frames == 1;
+    for (auto& k : m->r) (void)vr_hint_frames_in_flight(k.ctx, m->one_stream ? 1 : (m->slots > 4 ? 4 : m->slots));
     return VR_OK;
 }
 

@@ -157,11 +157,8 @@ struct vr_ctx {
                               // launches in flight, where workgroups start as others retire: 0.522 against 0.502 ms per C3 frame, so off)
     unsigned p2_window = 0;   // flavours 16 / 17: records per gather window (VR_EXP_P2_WINDOW: the moving window of volumes >= 4 GiB, forced
                               // onto small volumes by the tests; 0 = what the hardware reaches, just below 4 GiB)
-    bool pw_steal = false;    // ... and take other classes' packets once their own class is exhausted (VR_EXP_PW_STEAL=1: measured
-                              // 2-4 % slower -- the classes are even when a tile's packets are dealt over them)
     double active_fraction = 1.0;  // share of bricks that are not inert, of the distance field in use
     int pw_policy = 1;        // the default (flavour 0) may pick the persistent kernel (VR_EXP_PW_POLICY=0: never)
-    int pw_xcd_mode = -1;     // xcd_mode of persistent launches (VR_EXP_PW_XCD; -1 = the context's xcd_mode)
     std::string err;
 };
 
@@ -329,8 +326,8 @@ void fill_frame_params(MarchParams& P, const vr_uniforms& u)
 // launch order exists (the trial then measures what the steady state runs) -- and reads the launches' durations from
 // the pinned words their sorts fill (no synchronisation: a trial is evaluated when its last word has arrived; until then the
 // prior runs).  One launch at a time: the shortest first-start-to-last-end span of a candidate's launches but its first.  Launches
-// in flight: the mean interval between the ends of its consecutive launches (each of which ran beside launches of the same
-// candidate only: the first and the last one of a candidate's turn are not used).  The trial re-opens when the scene, the tables,
+// in flight: the mean interval between the ends of its consecutive launches that ran beside launches of the same candidate only
+// (3 x in_flight + 2 launches per turn, the first and the last in_flight of them not used).  The trial re-opens when the scene, the tables,
 // the launch shape or the frames-in-flight hint change (the key) and when the longest ray chain has moved by a quarter.
 int tune_pick(vr_ctx* c, unsigned long long key, const int* cand, int n, unsigned chain_now, bool measurable)
 {
@@ -347,7 +344,7 @@ int tune_pick(vr_ctx* c, unsigned long long key, const int* cand, int n, unsigne
             if (cand[i] != first && e.n < 4) e.cand[e.n++] = cand[i];
         e.cur = 0;
         e.issued = 0;
-        e.per = in_flight > 1 ? in_flight + 3 : 3;
+        e.per = in_flight > 1 ? 3 * in_flight + 2 : 3;
         e.settle = in_flight + 3;
         e.choice = -1;
         e.chain_ref = 0;
@@ -407,9 +404,11 @@ int tune_pick(vr_ctx* c, unsigned long long key, const int* cand, int n, unsigne
     for (int i = 0; i < t->n; ++i) {
         double ticks;
         if (in_flight > 1) {
-            const unsigned long long e0 = *(volatile unsigned long long*)&c->h_end[t->launch0[i] % kRing];
-            const unsigned long long e1 = *(volatile unsigned long long*)&c->h_end[(t->launch0[i] + t->per - 2) % kRing];
-            ticks = e1 > e0 ? (double)(e1 - e0) / (double)(t->per - 2) : 1.0e18;
+            // (its first `in_flight` launches ran beside the candidate before it, its last ones beside the next: the ends of the
+            // launches in between are `in_flight + 2` intervals apart that are this candidate's alone)
+            const unsigned long long e0 = *(volatile unsigned long long*)&c->h_end[(t->launch0[i] + in_flight) % kRing];
+            const unsigned long long e1 = *(volatile unsigned long long*)&c->h_end[(t->launch0[i] + t->per - in_flight) % kRing];
+            ticks = e1 > e0 ? (double)(e1 - e0) / (double)(t->per - 2 * in_flight) : 1.0e18;
         } else {
             ticks = 1.0e18;
             for (int q = 1; q < t->per; ++q) {
@@ -738,7 +737,6 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // large launches, where 4x the workgroups cost more at dispatch than the finer order gains (C2: 32 768 workgroups of
         // a 0.12 ms frame)
         const bool pw = fl == 12 || fl == 13 || fl == 16 || fl == 17;
-        if (pw && c->pw_xcd_mode >= 0) P.xcd_mode = c->pw_xcd_mode;
         int wpb = wtb ? 4 : ((pw || fl == 15) ? 1 : c->waves_per_block);
         if (dp && P.n_tiles * (dp == 4 ? 256 : 128) > 16384) wpb = 4;
         dim3 block((unsigned)(64 * wpb));
@@ -828,7 +826,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.pw_p2_skip = false;
             L.pw_p2_win = false;
             L.lds_bytes = 0;
-            L.queue = PwQueue{nullptr, 0u, 0u, 0u, 0u};
+            L.queue = PwQueue{nullptr, 0u, 0u, 0u};
             L.mixed_items = nullptr;
             L.n_logical = 0;
             L.grid = grid;
@@ -873,14 +871,13 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 L.lds_bytes = p2 ? p2_lds : (L.pw_ltf ? (unsigned)(c->tf[0].res_o + 2) * 16u : 0u);
                 L.queue.heads = c->d_pw_heads + (size_t)cb * 8 * 64;
                 L.queue.n_items = grid.x;
-                L.queue.steal = c->pw_steal ? 1u : 0u;
                 L.queue.p2_window = c->p2_window;
                 L.queue.dynamic = p2 && c->p2_dynq == 1 ? 1u : 0u;
                 const unsigned max_wgs = (unsigned)c->n_cus * wg_per_cu;
                 L.grid = dim3(wgs < max_wgs ? wgs : max_wgs);
                 L.block = dim3(pw_threads);
                 if (c->pw_heads_dirty[cb]) VR_HIP(c, hipMemsetAsync(L.queue.heads, 0, 8 * 64 * sizeof(unsigned), s));
-                c->pw_heads_dirty[cb] = !ordered;  // (an ordered launch's sort clears them behind it)
+                c->pw_heads_dirty[cb] = true;  // (until the sort that clears them behind this launch has really been enqueued: below)
             }
             if (mixed_items) {
                 L.mixed_items = mixed_items;
@@ -921,6 +918,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                                pw ? c->d_pw_heads + (size_t)cb * 8 * 64 : (unsigned*)nullptr,
                                (c->h_span && c->h_end && !time_with_events) ? c->h_end + slot : (unsigned long long*)nullptr);
             VR_HIP(c, hipGetLastError());
+            if (pw) c->pw_heads_dirty[cb] = false;  // (the sort zeroes the heads behind the launch: the slot's next user finds them clean)
             o.has_items = false;
 #if VR_EXPERIMENTAL_FLAVOURS
             if (fl == 14 && c->h_items && c->h_split) {
@@ -1034,9 +1032,20 @@ int refresh_bricks(vr_ctx* c, int slot)
             c->vol_bricked[slot] = nullptr;
             c->vol_bdens[slot] = nullptr;
             c->vol_bricked_cap[slot] = 0;
-            VR_HIP(c, hipMalloc(&c->vol_bricked[slot], slots * sizeof(float4)));
-            VR_HIP(c, hipMalloc(&c->vol_bdens[slot], slots * sizeof(float)));
-            c->vol_bricked_cap[slot] = slots;
+            // (the bricked copies cost 20 B per voxel on top of the reference layout's 16 + 4: when they do not fit, the kernels gather
+            // from the x-fastest arrays as with vr_set_volume_layout(3) -- slower, not an error)
+            if (hipMalloc(&c->vol_bricked[slot], slots * sizeof(float4)) != hipSuccess) c->vol_bricked[slot] = nullptr;
+            if (c->vol_bricked[slot] && hipMalloc(&c->vol_bdens[slot], slots * sizeof(float)) != hipSuccess) {
+                (void)hipFree(c->vol_bricked[slot]);
+                c->vol_bricked[slot] = nullptr;
+                c->vol_bdens[slot] = nullptr;
+            }
+            (void)hipGetLastError();
+            c->vol_bricked_cap[slot] = c->vol_bricked[slot] ? slots : 0;
+        }
+        if (!c->vol_bricked[slot]) {
+            VR_HIP(c, hipStreamSynchronize(c->stream));
+            return VR_OK;
         }
         hipLaunchKernelGGL(rebrick_kernel, dim3(8192), dim3(256), 0, c->stream, v.data, c->vol_bricked[slot], c->vol_bdens[slot], v.nx,
                            v.ny, v.nz, nbx, nby, slots);
@@ -1213,7 +1222,6 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     }
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
-    if (const char* e = getenv("VR_EXP_PW_STEAL")) c->pw_steal = atoi(e) != 0;
     if (const char* e = getenv("VR_EXP_P2_THREADS")) {
         const int t = atoi(e);
         if (t >= 64 && t <= 768 && t % 64 == 0) c->p2_threads = (unsigned)t;
@@ -1226,7 +1234,6 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     }
     if (const char* e = getenv("VR_EXP_PW_POLICY")) c->pw_policy = atoi(e);
     if (const char* e = getenv("VR_EXP_TUNE")) c->tune_mode = atoi(e);
-    if (const char* e = getenv("VR_EXP_PW_XCD")) c->pw_xcd_mode = atoi(e);
     if (!hip_ok(hipMalloc(&c->d_pw_heads, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMalloc(queue heads)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipMemset(c->d_pw_heads, 0, (size_t)kInFlight * 8 * 64 * sizeof(unsigned)), "hipMemset(queue heads)")) return bail(VR_ERR_HIP);
     if (!hip_ok(hipEventCreate(&c->tm.ev_begin), "hipEventCreate")) return bail(VR_ERR_HIP);
@@ -1569,6 +1576,38 @@ int vr_present_tiles_async(vr_ctx* c, const void* d_gathered, int world, int ran
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     dim3 block(64, 4), grid((c->W + 63) / 64, (c->H + 3) / 4);
     hipLaunchKernelGGL(present_tiles_kernel, grid, block, 0, s, (const float4*)d_gathered, (uint32_t*)d_bgra8, (int)c->W, (int)c->H,
+                       tiles_x_of(c), world, rank_stride_tiles);
+    VR_HIP(c, hipGetLastError());
+    return VR_OK;
+}
+
+int vr_present_packed_async(vr_ctx* c, const void* d_tiles_rgba, int n_tiles, void* d_tiles_bgra8, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!d_tiles_rgba || !d_tiles_bgra8 || n_tiles < 0) return fail(c, VR_ERR_INVALID_ARG, "vr_present_packed_async: bad arguments");
+    if (n_tiles == 0) return VR_OK;
+    VR_HIP(c, hipSetDevice(c->device));
+    (void)hipGetLastError();
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t n = (size_t)n_tiles * kTile * kTile;
+    if (n > 0x7fffffffull) return fail(c, VR_ERR_INVALID_ARG, "vr_present_packed_async: too many tiles");
+    hipLaunchKernelGGL(present_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float4*)d_tiles_rgba, (uint32_t*)d_tiles_bgra8, (int)n);
+    VR_HIP(c, hipGetLastError());
+    return VR_OK;
+}
+
+int vr_unpack_tiles_bgra8_async(vr_ctx* c, const void* d_gathered_bgra8, int world, int rank_stride_tiles, void* d_bgra8, void* stream)
+{
+    if (!c) return VR_ERR_INVALID_ARG;
+    if (!d_gathered_bgra8 || !d_bgra8 || world < 1) return fail(c, VR_ERR_INVALID_ARG, "vr_unpack_tiles_bgra8_async: bad arguments");
+    const int tpr = tile_count(c, 0, world);
+    if (rank_stride_tiles <= 0) rank_stride_tiles = tpr;
+    if (rank_stride_tiles < tpr) return fail(c, VR_ERR_INVALID_ARG, "vr_unpack_tiles_bgra8_async: stride smaller than a segment");
+    VR_HIP(c, hipSetDevice(c->device));
+    (void)hipGetLastError();
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    dim3 block(64, 4), grid((c->W + 63) / 64, (c->H + 3) / 4);
+    hipLaunchKernelGGL(unpack_tiles_u32_kernel, grid, block, 0, s, (const uint32_t*)d_gathered_bgra8, (uint32_t*)d_bgra8, (int)c->W, (int)c->H,
                        tiles_x_of(c), world, rank_stride_tiles);
     VR_HIP(c, hipGetLastError());
     return VR_OK;

@@ -129,7 +129,6 @@ struct MarchBatch {
 struct PwQueue {
     unsigned* heads;
     unsigned n_items;  // logical blocks of the launch (a multiple of 8)
-    unsigned steal;    // 1: a wavefront whose class is exhausted takes items of the other classes
     unsigned dynamic;    // march_p2_kernel: 1 = a wavefront's first item comes from the heads as well (no static deal)
     unsigned p2_window;  // march_p2_kernel<.., WIN>: records per gather window when not 0 (tests: a small window on a small volume)
 };

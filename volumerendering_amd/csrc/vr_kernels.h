@@ -1719,6 +1719,20 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4*
     frame[(size_t)y * W + x] = gathered[src];
 }
 
+// ... and the same un-permute for tiles that were presented where they were rendered (4 B per pixel: the multi-GPU loop gathers
+// BGRA8 tiles instead of float tiles when only the presented frame is wanted)
+__global__ void unpack_tiles_u32_kernel(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame, int W, int H, int tiles_x,
+                                        int world, int tiles_per_rank_max)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    int t = (y / kTile) * tiles_x + (x / kTile);
+    int r = t % world, n = t / world;
+    size_t src = ((size_t)r * tiles_per_rank_max + n) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile);
+    frame[(size_t)y * W + x] = gathered[src];
+}
+
 // One block: adds the per-block counts of the last march launch up (out[0..2]).
 __global__ __launch_bounds__(256) void sum_block_counts_kernel(const unsigned long long* __restrict__ in, int n_blocks,
                                                                unsigned long long* __restrict__ out)

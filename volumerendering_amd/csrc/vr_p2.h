@@ -234,18 +234,9 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
         idx = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
     }
     typedef typename std::conditional<kLit, vr_f4, float>::type Elem;
-    unsigned cur = cls, tried = 0;  // (stealing between classes: march_pw_kernel's)
+    const unsigned cur = cls;
     for (;;) {
-        if (idx >= n_c) {
-            if (!Q.steal || ++tried >= 8u) break;
-            cur = (cur + 1u) & 7u;
-            const unsigned groups_o = (gridDim.x - cur + 7u) >> 3;
-            unsigned r = 0;
-            if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
-            idx = (Q.dynamic ? 0u : groups_o * wpb) + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
-            continue;
-        }
-        tried = 0;
+        if (idx >= n_c) break;  // (the class's queue has run dry: the wavefront leaves)
         // item idx of the class = packet idx / nf (in the launch order) of frame idx % nf
         unsigned item = idx, frame = 0;
         if constexpr (BATCH) {
@@ -565,8 +556,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
 #endif
         unsigned r = 0;
         if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
-        const unsigned groups_cur = (gridDim.x - cur + 7u) >> 3;
-        idx = (Q.dynamic ? 0u : groups_cur * wpb) + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+        idx = (Q.dynamic ? 0u : groups * wpb) + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
     }
 }
 

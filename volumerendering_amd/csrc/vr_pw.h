@@ -58,22 +58,12 @@ __global__ __launch_bounds__(kPwThreads) void march_pw_kernel(const MarchBatch B
     const unsigned n_c = Q.n_items >> 3;                  // items per class (n_items is a multiple of 8)
     // first item: static, wavefront k of every workgroup before wavefront k + 1 of any (the order is longest first)
     unsigned idx = wib * groups + (blockIdx.x >> 3);
-    // A wavefront whose class has run dry goes on with the next class's queue (Q.steal; a class is an XCD's share of the
-    // packets: with whole tiles per class -- xcd_mode 0: the 64 packets of a tile share an L2 -- the classes' work differs by a
-    // factor of 1.5, which stealing evens out at the end of the launch).  Every item is still handed out exactly once: item
-    // index = the head's old value + the number of that class's static items.
-    unsigned cur = cls, tried = 0;
+    // (A wavefront whose class has run dry leaves.  Round 3 let it go on with the next class's queue -- 2-4 % slower, the classes
+    // are even when a tile's sub-blocks are dealt over them -- and whole tiles per class with stealing -- less fabric traffic, 9 %
+    // slower: both knobs were removed in round 4, their measurements are in HISTORY.md.)
+    const unsigned cur = cls;
     for (;;) {
-        if (idx >= n_c) {
-            if (!Q.steal || ++tried >= 8u) break;
-            cur = (cur + 1u) & 7u;
-            const unsigned groups_o = (gridDim.x - cur + 7u) >> 3;
-            unsigned r = 0;
-            if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
-            idx = groups_o * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
-            continue;
-        }
-        tried = 0;
+        if (idx >= n_c) break;
         const unsigned pos = (idx << 3) | cur;
         int lb = (int)pos;
         if (P.order != nullptr) lb = __builtin_amdgcn_readfirstlane((int)P.order[pos]);
@@ -86,8 +76,7 @@ __global__ __launch_bounds__(kPwThreads) void march_pw_kernel(const MarchBatch B
         store_wave_counts(P, lb, blends, covered, fetched, t_start);
         unsigned r = 0;
         if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
-        const unsigned groups_cur = (gridDim.x - cur + 7u) >> 3;
-        idx = groups_cur * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+        idx = groups * wpb + (unsigned)__builtin_amdgcn_readfirstlane((int)r);
     }
 }
 
