@@ -89,6 +89,13 @@ def main():
             print(f"[loop counters] {name}: n {sel.sum()}  median duration {np.median(dur[sel]):.0f} us  trips {np.median(trips[sel]):.0f}  sampled steps {np.median(smp[sel]):.0f}"
                   f"  shaded steps {np.median(shd[sel]):.0f}  jumps {np.median(jmp[sel]):.0f}  chain {np.median(crit[sel]):.0f}"
                   f"  us per trip {np.median(dur[sel] / np.maximum(1, trips[sel])):.2f}")
+    if os.environ.get("VR_P2_DEBUG") == "2":  # (-DVR_P2_DEBUG=2: the covered word holds wait cycles / 64)
+        c = tr[:, 1]
+        wc, wb, lp = (c & 0xfffff) * 64.0, ((c >> 20) & 0xfffff) * 64.0, ((c >> 40) & 0xffffff) * 64.0
+        busy = lp > 0
+        print(f"[wait cycles] packets {busy.sum()}: pipelined loop {lp[busy].sum() / 1e6:.1f} Mcycles, waiting for corners {wc[busy].sum() / 1e6:.1f} "
+              f"({100 * wc[busy].sum() / lp[busy].sum():.1f} %), for the distance-field bytes {wb[busy].sum() / 1e6:.1f} ({100 * wb[busy].sum() / lp[busy].sum():.1f} %); "
+              f"median per packet: loop {np.median(lp[busy]):.0f} corners {np.median(wc[busy]):.0f} bytes {np.median(wb[busy]):.0f} cycles")
     # residency over time (20 bins)
     edges = np.linspace(0, span, 21)
     res = []

@@ -26,7 +26,7 @@ def newest(pattern):
 def main():
     for f in sorted(glob.glob(os.path.join(SRC, "*.json"))):
         name = os.path.basename(f)[:-5]
-        if name.startswith("trace"):
+        if name.startswith(("trace", "pmc_probe")):
             continue
         try:
             d = load(f)
@@ -53,8 +53,10 @@ def main():
         f = newest(os.path.join(SRC, t, "*", "*kernel_stats.csv"))
         if f:
             shutil.copyfile(f, os.path.join(DST, dst))
+    for js in glob.glob(os.path.join(SRC, "pmc_probe_*.json")):
+        shutil.copyfile(js, os.path.join(DST, f"r{RND}_" + os.path.basename(js)))
     for txt in glob.glob(os.path.join(SRC, "*.txt")):
-        if os.path.basename(txt).startswith(("block_trace", "valu_issue")):
+        if os.path.basename(txt).startswith(("block_trace", "valu_issue", "struct_buffer")):
             shutil.copyfile(txt, os.path.join(DST, f"r{RND}_" + os.path.basename(txt)))
     f = newest(os.path.join(SRC, "ubench_pmc", "*", "*counter_collection.csv"))
     if f:

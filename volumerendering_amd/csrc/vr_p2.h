@@ -95,26 +95,46 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t p2_descriptor(const P2Win& win
 template <int V>
 constexpr unsigned p2_window_slots() { return V == V_BASIC ? 0x3fffffffu : 0x0fffffffu; }  // records x stride < 4 GiB
 
-// Requests the eight corners of position q into X, returns the interpolation weights.  MASKED: the lanes that say `idle`
-// request nothing, and the distance-field byte of q's brick (VOLUME_MASK: and the brick's mask record) is asked for just
+// Requests the eight corners of position q into X, returns the interpolation weights.  MASKED: only the lanes of `keep`
+// request anything, and the distance-field byte of q's brick (VOLUME_MASK: and the brick's mask record) is asked for just
 // ahead of the corners, by every lane -- the skipping's bricks ARE the layout's bricks (brick_of(q) is the base cell's brick:
 // see its comment), so the byte's index is the base corner's slot without its six intra-brick bits.
 // WIN: `need` = the lanes whose corners will be consumed (marching, not idle); when one of them leaves the window it is
 // re-centred on them (no memory instruction in that block); a packet that does not fit a window at all (never seen: the
 // rays of a packet are voxels apart) ends the pipelined loop -- n_in_w = 0 -- and the plain loop behind it finishes the packet.
-template <int V, bool MASKED, bool WIN, typename T>
-__device__ __forceinline__ void p2_request(const MarchParams& P0, const DevVolume& vol, const P2Lds& L, P2Win& win, int& n_in_w, f3 q, T (&X)[8], float& fx, float& fy, float& fz, bool idle, bool need, unsigned& dbyte,
-                                           float& mrec)
+// (in two parts, so that the tables' LDS latency runs under the interpolation of the step being consumed: p2_address -- the cell's
+// coordinates, weights and the three table reads, anywhere before -- and p2_issue -- slots, window, byte, loads -- once the old
+// corners are dead)
+struct P2Addr {
+    uint2 ex, ey, ez;   // slot terms of the texel pairs per axis
+    float fx, fy, fz;   // interpolation weights
+    int tz;             // base cell's z (the window's test)
+};
+__device__ __forceinline__ P2Addr p2_address(const DevVolume& vol, const P2Lds& L, f3 q)
 {
+    P2Addr a;
     const float x = mad(q.x, (float)vol.nx, -0.5f), y = mad(q.y, (float)vol.ny, -0.5f), z = mad(q.z, (float)vol.nz, -0.5f);
     const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
-    fx = x - x0;
-    fy = y - y0;
-    fz = z - z0;
+    a.fx = x - x0;
+    a.fy = y - y0;
+    a.fz = z - z0;
     // (saturating conversions, NaN -> 0; the clamp to [-1, n-1] selects the same texel pair as texel_pair() for ANY value)
-    const int tx = min(max((int)x0, -1), L.mx), ty = min(max((int)y0, -1), L.my), tz = min(max((int)z0, -1), L.mz);
-    const uint2 ex = lds_pair(L.off_x + ((unsigned)(tx + 1) << 3)), ey = lds_pair(L.off_y + ((unsigned)(ty + 1) << 3)),
-                ez = lds_pair(L.off_z + ((unsigned)(tz + 1) << 3));
+    const int tx = min(max((int)x0, -1), L.mx), ty = min(max((int)y0, -1), L.my);
+    a.tz = min(max((int)z0, -1), L.mz);
+    a.ex = lds_pair(L.off_x + ((unsigned)(tx + 1) << 3));
+    a.ey = lds_pair(L.off_y + ((unsigned)(ty + 1) << 3));
+    a.ez = lds_pair(L.off_z + ((unsigned)(a.tz + 1) << 3));
+    return a;
+}
+template <int V, bool MASKED, bool WIN, typename T>
+__device__ __forceinline__ void p2_issue(const MarchParams& P0, const DevVolume& vol, const P2Lds& L, P2Win& win, int& n_in_w, const P2Addr& a, T (&X)[8],
+                                         float& fx, float& fy, float& fz, unsigned long long keep, bool need, unsigned& dbyte, float& mrec)
+{
+    fx = a.fx;
+    fy = a.fy;
+    fz = a.fz;
+    const uint2 ex = a.ex, ey = a.ey, ez = a.ez;
+    const int tz = a.tz;
     unsigned az0 = ez.x, az1 = ez.y;
     if constexpr (WIN) {
         az0 -= win.base;
@@ -152,7 +172,6 @@ __device__ __forceinline__ void p2_request(const MarchParams& P0, const DevVolum
     unsigned long long exec_saved = 0;
     if constexpr (MASKED) {
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]));
-        const unsigned long long keep = vr_ballot(!idle);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1" : "=&s"(exec_saved) : "s"(keep) : "scc");
     }
@@ -166,6 +185,26 @@ __device__ __forceinline__ void p2_request(const MarchParams& P0, const DevVolum
         asm volatile("s_mov_b64 exec, %0" : : "s"(exec_saved));
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int V, bool MASKED, bool WIN, typename T>
+__device__ __forceinline__ void p2_request(const MarchParams& P0, const DevVolume& vol, const P2Lds& L, P2Win& win, int& n_in_w, f3 q, T (&X)[8], float& fx,
+                                           float& fy, float& fz, unsigned long long keep, bool need, unsigned& dbyte, float& mrec)
+{
+    const P2Addr a = p2_address(vol, L, q);
+    p2_issue<V, MASKED, WIN>(P0, vol, L, win, n_in_w, a, X, fx, fy, fz, keep, need, dbyte, mrec);
+}
+
+// The smallest value of a full wavefront (every lane active): four v_min_i32 through the DPP cross-bar (neighbour, pair, half row,
+// row: every lane of a row of 16 then holds the row's minimum), the four rows' values read as scalars.  No LDS round trip
+// (__shfl_xor goes through ds_bpermute: six dependent LDS latencies), nine instructions.
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm:[1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm:[2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // The per-step vote of sample_and_blend (opacity_is_zero for every sampling ray) as ONE compare: the table index that decides,
@@ -261,6 +300,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
         unsigned blends = 0, covered = 0, fetched = 0;
 #if VR_P2_DEBUG
         unsigned dbg_trips = 0, dbg_sampled = 0, dbg_shaded = 0, dbg_jumps = 0;
+        unsigned long long dbg_wait_corners = 0, dbg_wait_bytes = 0, dbg_loop = 0;  // (VR_P2_DEBUG=2: shader-clock cycles)
 #endif
         bool alive = false;
         f3 p = mk3(0.0f, 0.0f, 0.0f), w = p, step = p, wstep = p;
@@ -331,13 +371,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             int i = 0;  // the step pA is at (wave-uniform)
             // steps every marching ray of the packet is certainly in time and inside the box for (wave-uniform): before that
             // step no ray needs the box test
-            int n_in_w;
-            {
-                int v = alive ? min(n_inside, steps_count) : 0x7fffffff;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-                n_in_w = __builtin_amdgcn_readfirstlane(v);
-            }
+            int n_in_w = wave_min_i32(alive ? min(n_inside, steps_count) : 0x7fffffff);
             // the gather source: the bricked vec4 voxels (lit) or the bricked density plane (unlit) as records of an indexed buffer
             P2Win win;
             p2_set_window<V>(win, vol, 0u, WIN ? min(total_slots, L.win_slots) : total_slots);
@@ -361,6 +395,10 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                                 float& MX) {
                 const bool inb = alive;  // (in time and inside the box: the loop's condition)
                 const bool sampled = SKIP ? (inb && !idle_con) : inb;
+                // the position of the next request into X, and its cell's table reads: in flight under this step's interpolation
+                f3 pN = mk3(pY.x + step.x, pY.y + step.y, pY.z + step.z);
+                for (int k = 0; k < jump; ++k) pN = mk3(pN.x + step.x, pN.y + step.y, pN.z + step.z);
+                const P2Addr ad = p2_address(vol, L, pN);
                 v2f zw = v2f{0.0f, 0.0f}, gxy = zw;
                 TfFetch tq;
                 float4 mask = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // VOLUME_MASK: the interpolated mask and dose of pX
@@ -371,6 +409,19 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
 #if VR_P2_DEBUG
                 if (shaded) ++dbg_sampled;
 #endif
+                if (shaded) {
+                    // ONE wait for the buffer: its corners arrived long ago (a -DVR_P2_DEBUG=2 build clocks this wait: 0.2 - 0.6 % of a
+                    // packet's cycles, gpurun_out/r4k), so the four partial waits the compiler places (one per pair of corners as the
+                    // interpolation reaches it) buy nothing and cost three scalar instructions
+#if VR_P2_DEBUG >= 2
+                    const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
+                    if constexpr (kLit) asm volatile("" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]));
+                    else asm volatile("" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]));
+#if VR_P2_DEBUG >= 2
+                    dbg_wait_corners += __builtin_readcyclecounter() - c0;
+#endif
+                }
                 if (!shaded) {
                 } else if constexpr (kLit) {
                     Fetch4 q;
@@ -412,11 +463,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     if constexpr (SKIP) shaded = p2_vote(P0, sampled, zw.y);
                     if (shaded) tq = tf_fetch_lds(P0.tf[0], zw.y);
                 }
-                const f3 pC = pX;  // (VOLUME_MASK reads nothing of it below: the mask was fetched above)
-                (void)pC;
-                // the position of the next request into X
-                pX = mk3(pY.x + step.x, pY.y + step.y, pY.z + step.z);
-                for (int k = 0; k < jump; ++k) pX = mk3(pX.x + step.x, pX.y + step.y, pX.z + step.z);
+                pX = pN;  // (VOLUME_MASK has fetched its mask at the consumed position above)
                 // Everything that reads the old corners must be COMPUTED here, before their registers are loaded again: left alone,
                 // the compiler sinks the gradient's interpolation into the `if (sampled)` below (its only user), the old corners
                 // then live across the new loads, the new loads get other registers, and the copies that bring them back at the
@@ -425,8 +472,9 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 else asm volatile("" : "+v"(zw.y));
                 __builtin_amdgcn_sched_barrier(0);  // the old corners are dead here: the new ones may land in their registers
                 // (with the byte of the position requested: the next trip decides with it)
-                const bool idle = SKIP && (idle_rq || !alive);
-                p2_request<V, SKIP, WIN>(P0, vol, L, win, n_in_w, pX, X, xfx, xfy, xfz, idle, alive && !idle, DX, MX);
+                // (the lanes that request: marching and not idle -- as the lane mask itself, taken before the slots are pinned)
+                const bool rq = alive && !(SKIP && idle_rq);
+                p2_issue<V, SKIP, WIN>(P0, vol, L, win, n_in_w, ad, X, xfx, xfy, xfz, vr_ballot(rq), rq, DX, MX);
                 __builtin_amdgcn_sched_barrier(0);
 #if VR_P2_DEBUG
                 if (shaded) ++dbg_shaded;
@@ -463,13 +511,14 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             bool start = true;  // (wave-uniform) nothing is in flight yet
 #if VR_P2_DEBUG
             dbg_trips = dbg_sampled = dbg_shaded = dbg_jumps = 0;
+            dbg_loop = __builtin_readcyclecounter();
 #endif
             while (i + 2 <= n_in_w && vr_ballot(alive) != 0) {
                 if (start) {
                     // the bytes of pA and pB and, without waiting for them, the corners of steps 0 and 1 of every ray
                     pB = mk3(pA.x + step.x, pA.y + step.y, pA.z + step.z);
-                    p2_request<V, SKIP, WIN>(P0, vol, L, win, n_in_w, pA, A, afx, afy, afz, SKIP && !alive, alive, DA, MA);
-                    p2_request<V, SKIP, WIN>(P0, vol, L, win, n_in_w, pB, Bq, bfx, bfy, bfz, SKIP && !alive, alive, DB, MB);
+                    p2_request<V, SKIP, WIN>(P0, vol, L, win, n_in_w, pA, A, afx, afy, afz, vr_ballot(alive), alive, DA, MA);
+                    p2_request<V, SKIP, WIN>(P0, vol, L, win, n_in_w, pB, Bq, bfx, bfy, bfz, vr_ballot(alive), alive, DB, MB);
                     start = false;
                     if constexpr (WIN) {
                         if (n_in_w == 0) break;  // (the packet's first cells do not fit one window: the plain loop takes all of it)
@@ -486,6 +535,13 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     // no latency exposed.
                     // (A finished ray is folded into the VALUES -- byte 255, any number of safe steps -- so that every vote below is
                     // the lane mask of ONE compare: a vote on `alive && x < k` costs a mask AND, a v_cndmask and a second compare.)
+#if VR_P2_DEBUG >= 2
+                    {
+                        const unsigned long long c0 = __builtin_readcyclecounter();
+                        asm volatile("" : "+v"(DA), "+v"(DB));
+                        dbg_wait_bytes += __builtin_readcyclecounter() - c0;
+                    }
+#endif
                     unsigned da = alive ? DA : 255u, db = alive ? DB : 255u;
                     asm volatile("" : "+v"(da), "+v"(db));  // (kept as values: the compiler would turn `da >= 1` back into mask logic)
                     idle_a = da >= 1u;
@@ -493,16 +549,10 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     // steps after pB the ray certainly spends in inert bricks (march_packet's run length; < 0 at an active brick)
                     int m = min((int)fminf(((float)db - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - (i + 1) - 1);
                     m = alive ? m : 64;
-                    if (vr_ballot(m < 4) == 0) {
-                        mw = 4;
-                        if (vr_ballot(m < 8) == 0) {
-                            mw = 8;
-                            if (vr_ballot(m < 16) == 0) {
-                                mw = 16;
-                                if (vr_ballot(m < 32) == 0) mw = vr_ballot(m < 64) == 0 ? 64 : 32;
-                            }
-                        }
-                    }
+                    // (Round 3 jumped by 4, 8 .. 64 steps, decided by up to five votes: a gap of one to three steps -- the packet's rays
+                    // reach an active brick a few steps apart -- was walked as idle steps, each the price of a request.  A jump costs
+                    // three additions per step: every marching ray's safe steps, however few, are jumped, by exactly their minimum.)
+                    if (vr_ballot(m < 1) == 0) mw = min(wave_min_i32(m), 64);
                     idle_ra = m >= mw + 1;  // the positions requested now are steps mw + 1 and mw + 2 after pB
                     idle_rb = m >= mw + 2;
                 }
@@ -520,6 +570,9 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 }
                 i += 2 + mw;
             }
+#if VR_P2_DEBUG
+            dbg_loop = __builtin_readcyclecounter() - dbg_loop;
+#endif
             // The last steps of the packet (pA is the exact position of step i, w its world position): the shader's loop as it
             // stands -- box test, identity steps by the distance-field byte, the far-bound exit -- with no loads ahead.
             if (!start) p = pA;
@@ -553,6 +606,11 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
         if ((threadIdx.x & 63) == 0)  // (debug build: the `fetched` word carries the loop's own counters instead)
             P.block_counts[(size_t)lb * kBlockRecord + 2] = (unsigned long long)(dbg_trips & 0xfffu) | ((unsigned long long)(dbg_sampled & 0xfffu) << 12) |
                                                            ((unsigned long long)(dbg_shaded & 0xfffu) << 24) | ((unsigned long long)(dbg_jumps & 0xfffu) << 36);
+#if VR_P2_DEBUG >= 2
+        if ((threadIdx.x & 63) == 0)  // (... and the `covered` word the cycles spent waiting for corners / bytes and in the pipelined loop, / 64)
+            P.block_counts[(size_t)lb * kBlockRecord + 1] = ((dbg_wait_corners >> 6) & 0xfffffull) | (((dbg_wait_bytes >> 6) & 0xfffffull) << 20) |
+                                                           (((dbg_loop >> 6) & 0xffffffull) << 40);
+#endif
 #endif
         unsigned r = 0;
         if ((threadIdx.x & 63u) == 0) r = atomicAdd(Q.heads + cur * kPwHeadStride, 1u);
