@@ -10,7 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
-HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+# (xnack-: the MI355X runs with XNACK off; code for "either" makes the compiler break every run of vector-memory instructions in
+# which a destination overlaps an earlier address register with an s_nop -- seven per request of march_p2_kernel.
+# VR_HIP_ARCH=gfx950 in the environment builds the generic form.)
+HIP_ARCH = os.environ.get("VR_HIP_ARCH", "gfx950:xnack-")
+HIP_FLAGS = ["-O3", "--offload-arch=" + HIP_ARCH, "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
              "-std=c++17", "-Wall", "-Wno-unused-function"]
 HOST_FLAGS = ["-O2", "-std=c++20", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall"]
 
@@ -53,7 +57,7 @@ def build_hip(force: bool = False) -> str:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, f"hipcc {name}.hip")
     if procs or force or _newer(target, objs):
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, *objs], check=True)
+        subprocess.run([HIPCC, "--offload-arch=" + HIP_ARCH, "-fPIC", "-shared", "-o", target, *objs], check=True)
     with open(stamp, "w") as fh:
         fh.write(want)
     return target

@@ -113,6 +113,7 @@ struct vr_ctx {
     // the caller's own frames and keeps the fastest by the launches' own records -- per "what is launched of what".
     struct Tune {
         unsigned long long key = 0;   // shader, share, viewport, frames per launch, frames in flight, scene epoch, arithmetic, layout (0 = free)
+        unsigned long long shape = 0; // ... the same without the scene's epochs: a new scene starts from what the last one of this shape kept
         int n = 0, cand[4] = {};      // the eligible flavours; cand[0] = the prior's pick (what runs while nothing is known)
         int cur = 0, issued = 0;      // candidate on trial, launches it has had
         int per = 3, settle = 4;      // launches per candidate; launches before the trial starts (no launch order exists yet)
@@ -329,7 +330,7 @@ void fill_frame_params(MarchParams& P, const vr_uniforms& u)
 // in flight: the mean interval between the ends of its consecutive launches that ran beside launches of the same candidate only
 // (3 x in_flight + 2 launches per turn, the first and the last in_flight of them not used).  The trial re-opens when the scene, the tables,
 // the launch shape or the frames-in-flight hint change (the key) and when the longest ray chain has moved by a quarter.
-int tune_pick(vr_ctx* c, unsigned long long key, const int* cand, int n, unsigned chain_now, bool measurable)
+int tune_pick(vr_ctx* c, unsigned long long key, unsigned long long shape, const int* cand, int n, unsigned chain_now, bool measurable)
 {
     if (n <= 1) return cand[0];
     vr_ctx::Tune* t = nullptr;
@@ -338,6 +339,7 @@ int tune_pick(vr_ctx* c, unsigned long long key, const int* cand, int n, unsigne
     const int in_flight = c->frames_in_flight;
     auto reset = [&](vr_ctx::Tune& e, int first) {
         e.key = key;
+        e.shape = shape;
         e.n = 0;
         e.cand[e.n++] = first;
         for (int i = 0; i < n; ++i)
@@ -354,10 +356,21 @@ int tune_pick(vr_ctx* c, unsigned long long key, const int* cand, int n, unsigne
         }
     };
     if (!t) {
+        // a new scene (or table, or arithmetic) of a shape that has been measured before: what that trial kept runs first, if it is
+        // still eligible -- a host that edits a table frame after frame keeps its kernel while every new trial settles
+        int first = cand[0];
+        unsigned long long newest = 0;
+        for (const auto& e : c->tune)
+            if (e.key != 0 && e.shape == shape && e.choice >= 0 && e.used > newest)
+                for (int i = 0; i < n; ++i)
+                    if (cand[i] == e.cand[e.choice]) {
+                        first = cand[i];
+                        newest = e.used;
+                    }
         t = &c->tune[0];
         for (auto& e : c->tune)
             if (e.used < t->used) t = &e;
-        reset(*t, cand[0]);
+        reset(*t, first);
     } else {
         // the eligible set may have changed under the same key (a flavour knob, a table that fits LDS no more)
         bool same = t->n == n;
@@ -690,12 +703,13 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         const bool dp_variant = variant != VR_VARIANT_ILLUSTRATIVE && variant != VR_VARIANT_LIGHT_INSHADER;
         if (!whole_frame && dp_variant) add((double)px_all * c->frames_in_flight * n_frames / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 2.0 ? 11 : 10);
         else if (n_frames == 1 && (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC)) add(12);
-        const unsigned long long key = 0x9E3779B97F4A7C15ull * (((unsigned long long)variant << 56) ^ ((unsigned long long)world << 48) ^ ((unsigned long long)rank << 40) ^
-                                                               ((unsigned long long)c->W << 24) ^ ((unsigned long long)c->H << 8) ^ (packed ? 0x80ull : 0ull) ^
-                                                               ((unsigned long long)n_frames << 4) ^ (unsigned long long)c->frames_in_flight) ^
-                                       (c->brick_epoch * 0xD6E8FEB86659FD93ull) ^ (c->tf_epoch << 20) ^ ((unsigned long long)c->arith << 1) ^ (unsigned long long)c->layout_mode ^ 1ull;
+        const unsigned long long shape = 0x9E3779B97F4A7C15ull * (((unsigned long long)variant << 56) ^ ((unsigned long long)world << 48) ^ ((unsigned long long)rank << 40) ^
+                                                                 ((unsigned long long)c->W << 24) ^ ((unsigned long long)c->H << 8) ^ (packed ? 0x80ull : 0ull) ^
+                                                                 ((unsigned long long)n_frames << 4) ^ (unsigned long long)c->frames_in_flight) | 1ull;
+        const unsigned long long key = (shape ^ (c->brick_epoch * 0xD6E8FEB86659FD93ull) ^ (c->tf_epoch << 20) ^ ((unsigned long long)c->arith << 1) ^
+                                        ((unsigned long long)c->layout_mode << 2)) | 1ull;
         const bool measurable = c->order_mode == 1 && c->h_span && c->h_end && !c->event_timing;
-        fl = tune_pick(c, key, cand, n, chain_known, measurable);
+        fl = tune_pick(c, key, shape, cand, n, chain_known, measurable);
     }
     c->last_flavour = fl;
 

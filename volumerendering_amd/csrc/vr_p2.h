@@ -247,11 +247,24 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
         L.win_slots = WIN ? (Q.p2_window ? Q.p2_window : p2_window_slots<V>()) : 0u;
         L.win_slabs = WIN ? L.win_slots / vol.brick_slab : 0u;
         L.win_last = WIN ? (L.win_slabs - 2u) * vol.brick_slab + (kVbM << (2u * kVbS)) : 0u;
+        // (the table's loads of six entries per thread in flight together: the launch waits for one memory latency here, not for
+        // one per 768 entries -- this copy is in front of every packet of the launch)
         const int n = P0.tf[0].res_o + 2;
-        for (int j = (int)threadIdx.x; j < n; j += (int)blockDim.x) {
-            float4 c = P0.tf[0].color[j];
-            c.w = P0.tf[0].opacity[j];
-            vr_lds_tf[j] = c;
+        constexpr int kU = 6;
+        for (int base = (int)threadIdx.x; base < n; base += kU * (int)blockDim.x) {
+            float4 c[kU];
+            float o[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int j = min(base + u * (int)blockDim.x, n - 1);
+                c[u] = P0.tf[0].color[j];
+                o[u] = P0.tf[0].opacity[j];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int j = base + u * (int)blockDim.x;
+                if (j < n) vr_lds_tf[j] = make_float4(c[u].x, c[u].y, c[u].z, o[u]);
+            }
         }
         p2_fill_tables(vol, L);
         __syncthreads();  // the only barrier: from here on the wavefronts are independent of each other
