@@ -96,6 +96,16 @@ def main():
         print(f"[wait cycles] packets {busy.sum()}: pipelined loop {lp[busy].sum() / 1e6:.1f} Mcycles, waiting for corners {wc[busy].sum() / 1e6:.1f} "
               f"({100 * wc[busy].sum() / lp[busy].sum():.1f} %), for the distance-field bytes {wb[busy].sum() / 1e6:.1f} ({100 * wb[busy].sum() / lp[busy].sum():.1f} %); "
               f"median per packet: loop {np.median(lp[busy]):.0f} corners {np.median(wc[busy]):.0f} bytes {np.median(wb[busy]):.0f} cycles")
+    if os.environ.get("VR_P2_DEBUG") == "3":  # (-DVR_P2_DEBUG=3: tail-loop cycles, whole-packet cycles, pipelined-loop cycles, / 64)
+        c = tr[:, 1]
+        tl, pk, lp = (c & 0xfffff) * 64.0, ((c >> 20) & 0xfffff) * 64.0, ((c >> 40) & 0xffffff) * 64.0
+        busy = lp > 0
+        print(f"[packet cycles] all packets {pk.sum() / 1e6:.1f} Mcycles; sampling packets ({busy.sum()}): whole {pk[busy].sum() / 1e6:.1f}, pipelined loop "
+              f"{lp[busy].sum() / 1e6:.1f} ({100 * lp[busy].sum() / pk[busy].sum():.1f} %), last steps (plain loop) {tl[busy].sum() / 1e6:.1f} "
+              f"({100 * tl[busy].sum() / pk[busy].sum():.1f} %), set-up and dequeue the rest; packets that never enter the pipelined loop: "
+              f"{(~busy).sum()} with {pk[~busy].sum() / 1e6:.1f} Mcycles")
+        long_ = busy & (pk > np.percentile(pk[busy], 75))
+        print(f"[packet cycles] longest quarter of the sampling packets: pipelined {100 * lp[long_].sum() / pk[long_].sum():.1f} %, last steps {100 * tl[long_].sum() / pk[long_].sum():.1f} %")
     # residency over time (20 bins)
     edges = np.linspace(0, span, 21)
     res = []

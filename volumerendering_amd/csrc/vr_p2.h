@@ -314,6 +314,8 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
 #if VR_P2_DEBUG
         unsigned dbg_trips = 0, dbg_sampled = 0, dbg_shaded = 0, dbg_jumps = 0;
         unsigned long long dbg_wait_corners = 0, dbg_wait_bytes = 0, dbg_loop = 0;  // (VR_P2_DEBUG=2: shader-clock cycles)
+        unsigned long long dbg_tail = 0;
+        const unsigned long long dbg_pkt0 = __builtin_readcyclecounter();
 #endif
         bool alive = false;
         f3 p = mk3(0.0f, 0.0f, 0.0f), w = p, step = p, wstep = p;
@@ -585,9 +587,15 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             }
 #if VR_P2_DEBUG
             dbg_loop = __builtin_readcyclecounter() - dbg_loop;
+            dbg_tail = __builtin_readcyclecounter();
 #endif
             // The last steps of the packet (pA is the exact position of step i, w its world position): the shader's loop as it
             // stands -- box test, identity steps by the distance-field byte, the far-bound exit -- with no loads ahead.
+            // (It also takes ALL the steps of a packet on the box's silhouette once its shortest ray may leave: 13 % of the sampling
+            // packets' cycles on C3, 3 % of the longest quarter's (-DVR_P2_DEBUG=3, gpurun_out/r4l).  Going back into the pipelined
+            // loop when the short rays have retired was built and measured: bit-exact, and SLOWER -- C3 0.525 -> 0.537 ms, C4 0.575
+            // -> 0.600 -- the values that then live across both loops cost spills, in the >= 4 GiB kernels between the two exec
+            // writes of p2_issue, where tools/check_exec_regions.py caught them.  Removed.)
             if (!start) p = pA;
             for (; i < steps_count && vr_ballot(alive) != 0; ++i) {
                 if (alive) {
@@ -613,6 +621,9 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 if constexpr (kLit) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
             }
         }
+#if VR_P2_DEBUG
+        if (dbg_tail) dbg_tail = __builtin_readcyclecounter() - dbg_tail;
+#endif
         if (slot.active || (P0.packed && slot.in_launch)) P.out[slot.out_index] = dst;
         store_wave_counts(P, lb, blends, covered, fetched, t_start);
 #if VR_P2_DEBUG
@@ -621,8 +632,13 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                                                            ((unsigned long long)(dbg_shaded & 0xfffu) << 24) | ((unsigned long long)(dbg_jumps & 0xfffu) << 36);
 #if VR_P2_DEBUG >= 2
         if ((threadIdx.x & 63) == 0)  // (... and the `covered` word the cycles spent waiting for corners / bytes and in the pipelined loop, / 64)
+#if VR_P2_DEBUG >= 3   // (3: the packet's whole time and its last steps' instead of the two waits)
+            P.block_counts[(size_t)lb * kBlockRecord + 1] = ((dbg_tail >> 6) & 0xfffffull) | ((((__builtin_readcyclecounter() - dbg_pkt0) >> 6) & 0xfffffull) << 20) |
+                                                           (((dbg_loop >> 6) & 0xffffffull) << 40);
+#else
             P.block_counts[(size_t)lb * kBlockRecord + 1] = ((dbg_wait_corners >> 6) & 0xfffffull) | (((dbg_wait_bytes >> 6) & 0xfffffull) << 20) |
                                                            (((dbg_loop >> 6) & 0xffffffull) << 40);
+#endif
 #endif
 #endif
         unsigned r = 0;
