@@ -1,53 +1,78 @@
 #!/usr/bin/env python3
-"""Prints the rows of DESIGN.md section 5's table from profiles/r02_*.json (run tools/collect_profiles.py first)."""
+"""Prints the rows of DESIGN.md section 5 / 6 from profiles/rNN_*.json (run tools/collect_profiles.py NN first):
+    python tools/design_table.py 04"""
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = sys.argv[1] if len(sys.argv) > 1 else "04"
 
 
 def load(name):
-    return json.load(open(os.path.join(ROOT, "profiles", f"r02_{name}.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", f"r{RND}_{name}.json")))
 
 
-def row(label, tf, name):
+def kept(leg):
+    k = (leg or {}).get("kernel_choice") or {}
+    return k.get("kept") or k.get("ran_last") or "-"
+
+
+def row(label, name):
     d = load(name)
     s, o, p = d["serial"], d["overlapped"], d.get("pipelined_one_frame_per_launch") or {}
-    c = d["config"]
-    return (f"| {label} | {tf} | {c['composited_samples_per_frame'] / 1e6:.1f} M / {c['fetched_samples_per_frame'] / 1e6:.1f} M | "
-            f"{s['kernel_ms_median']:.3f}, {s['ms_per_step']:.3f}, {s['value']:.0f} | {p.get('ms_per_step', 0):.3f}, {p.get('value', 0):.0f} | "
-            f"{o['ms_per_step']:.3f}, {o['fps']:.0f}, {o['value']:.0f} | {c.get('kernel_flavour_resolved')} |")
+    c, r = d["config"], d["roofline"]
+    pp = s.get("kernel_ms_p10_p90") or [0, 0]
+    tr = (r.get("traffic") or 0) / 1e9
+    return (f"| {label} | {c['composited_samples_frame0'] / 1e6:.1f} M / {c['fetched_samples_frame0'] / 1e6:.1f} M | "
+            f"{s['kernel_ms_median']:.3f} ({pp[0]:.3f}–{pp[1]:.3f}), {s['ms_per_step']:.3f}, **{s['value']:.0f}** | {p.get('ms_per_step', 0):.3f}, {p.get('value', 0):.0f} | "
+            f"{o['ms_per_step']:.3f}, {o['value']:.0f} | {tr:.2f} | {kept(s)} / {kept(p)} / {kept(o)} |" if tr else
+            f"| {label} | {c['composited_samples_frame0'] / 1e6:.1f} M / {c['fetched_samples_frame0'] / 1e6:.1f} M | "
+            f"{s['kernel_ms_median']:.3f} ({pp[0]:.3f}–{pp[1]:.3f}), {s['ms_per_step']:.3f}, **{s['value']:.0f}** | {p.get('ms_per_step', 0):.3f}, {p.get('value', 0):.0f} | "
+            f"{o['ms_per_step']:.3f}, {o['value']:.0f} | – | {kept(s)} / {kept(p)} / {kept(o)} |")
 
 
-for label, tf, name in [("C1", "default", "C1_default"), ("C2", "default", "C2_default"), ("C2", "thin", "C2_thin"),
-                        ("C3", "default", "bench_default"), ("C3 fused", "default", "c3_fused"), ("C3", "thin", "c3_thin"),
-                        ("C4", "default", "C4_default"), ("C4", "thin", "C4_thin"), ("C5", "default", "C5_default"), ("C5", "thin", "C5_thin"),
-                        ("C3 noisy", "default", "c3_noisy"), ("C3 flavour 1", "default", "c3_flavour1"), ("C3 no order", "default", "c3_noorder"),
-                        ("C3 wpb4", "default", "c3_wpb4"), ("C3 otf", "default", "c3_otf")]:
+print("| config | frame 0: composited / fetched | one frame at a time: kernel ms (p10–p90), ms / frame, **Gsamples/s** | 2 launches × 1 frame: ms, Gs/s | 2 × 4 frames: ms, Gs/s | fabric GB / frame | kernel kept (serial / pipelined / batched) |")
+print("|---|---|---|---|---|---|---|")
+for label, name in [("C1 sphere-64, 256², unlit", "C1_default"), ("C2 phantom-256, 1024², unlit", "C2_default"), ("C2, thin table", "C2_thin"),
+                    ("**C3 phantom-512, 1080p, lit — the driver's command** (`--steps 20 --warmup 5`)", "bench_default"),
+                    ("C3, 40 frames (yaw 0.6 → 1.08)", "c3_default"), ("C3, `march_kernel` forced (`--flavour 6`)", "c3_f6"),
+                    ("C3, two steps ahead forced in every leg (`--flavour 17`)", "c3_f17"), ("C3, fused arithmetic", "c3_fused"),
+                    ("C3, thin table", "c3_thin"), ("C3, noisy air (nothing to skip)", "c3_noisy"), ("C3, noisy air, `march_kernel`", "c3_noisy_f6"),
+                    ("**C4** C3 + mask + dose (3 volumes)", "C4_default"), ("C4, `march_kernel` forced", "C4_f6"), ("C4, thin", "C4_thin"),
+                    ("**C5** phantom-1024 (16 GiB), 4K, lit, 1 GPU", "C5_default"), ("C5, two steps ahead forced (the moving window)", "C5_f17"), ("C5, thin", "C5_thin")]:
     try:
-        print(row(label, tf, name))
+        print(row(label, name))
     except Exception as e:  # noqa: BLE001
         print(label, name, "missing", e)
-for n in (2, 4, 8):
-    for suffix in ("", "_k20"):
+print()
+for w in ("c3", "C5"):
+    for n in (2, 4, 8):
         try:
-            d = load(f"c3_share{n}{suffix}")
+            d = load(f"{w}_share{n}")
             p = d.get("pipelined_one_frame_per_launch") or {}
-            print(f"share {n}{suffix}: serial {d['serial']['ms_per_step']:.3f}  2x1 {p.get('ms_per_step', 0):.3f}  2x4 {d['overlapped']['ms_per_step']:.4f}")
+            o = d["overlapped"]
+            print(f"{w} share {n}: serial {d['serial']['ms_per_step']:.3f} (kernel {d['serial']['kernel_ms_median']:.3f}, {kept(d['serial'])})  2x1 {p.get('ms_per_step', 0):.3f} ({kept(p)})  "
+                  f"2x4 {o['ms_per_step']:.4f} ({kept(o)})")
         except Exception as e:  # noqa: BLE001
-            print("share", n, suffix, "missing", e)
+            print("share", w, n, "missing", e)
 d = load("c3_selfgather")
 print("selfgather", d["serial"]["ms_per_step"], (d.get("pipelined_one_frame_per_launch") or {}).get("ms_per_step"), d["overlapped"]["ms_per_step"])
-d = load("c3_default")
-r = d["roofline"]
-print("roofline c3_default: kernel", r["kernel_ms"], "frac", r["frac"], "frac_over", r["frac_overlapped"], "traffic GB", r["traffic"] / 1e9,
-      "valu", r["valu"]["busy_frac"], r["valu"]["busy_frac_overlapped"], "insts", r["valu"]["insts_per_launch"] / 1e6,
-      "l1", r["l1"]["frac"], r["l1"]["frac_overlapped"], "ta", r["l1"]["ta_busy_frac"], r["l1"]["ta_busy_frac_overlapped"],
-      "l1 bytes", r["l1"]["bytes_per_launch"] / 1e9, "gather", r["effective_gather"]["fetched_gbs"], "l2hit", r.get("l2_hit_rate"),
-      "serial ms", d["serial"]["ms_per_step"], "over", d["overlapped"]["ms_per_step"])
-if "regimes" in load("bench_default"):
-    for g in load("bench_default")["regimes"]:
-        print(g)
+for name in ("bench_default", "c3_default", "c3_f6", "c3_noisy", "C4_default", "C5_default"):
+    d = load(name)
+    r = d["roofline"]
+    v, l1 = r.get("valu") or {}, r.get("l1") or {}
+    print(f"roofline {name}: kernel_ms {r['kernel_ms']} frac {r['frac']} achieved {r['achieved']} traffic GB {(r.get('traffic') or 0) / 1e9:.3f} frac_over {r.get('frac_overlapped')} "
+          f"d2d {r.get('d2d_copy_gbs')} frac_d2d {r.get('frac_of_d2d_copy')} valu busy {v.get('busy_frac')} insts {(v.get('insts_per_launch') or 0) / 1e6:.1f} M "
+          f"ta {l1.get('ta_busy_frac')} l1frac {l1.get('frac')} l2hit {r.get('l2_hit_rate')} gather {r['effective_gather']['fetched_gbs']} / {r['effective_gather']['composited_gbs']} clock {v.get('clock_ghz')}")
 b = load("bench_default")
-print("cpu", b.get("cpu_baseline"))
+for k in ("sync_8d", "full_turn", "serial_with_present"):
+    print(k, {kk: vv for kk, vv in (b.get(k) or {}).items() if kk != "note"})
+for g in b.get("regimes", []):
+    print(g)
+print("cpu", {k: v for k, v in (b.get("cpu_baseline") or {}).items() if k not in ("cores_note", "speedup_note", "implementation")})
 print("parity", {k: v for k, v in (b.get("parity") or {}).items() if not isinstance(v, (list, dict))})
+print("arith_ab", b.get("arith_ab", {}).get("serial"), b.get("arith_ab", {}).get("overlapped"))
+for name in ("c3_share8", "C5_share8"):
+    d = load(name)
+    print(name, "timeline", json.dumps(d.get("rank0_stage_timeline"))[:900])
