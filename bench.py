@@ -574,9 +574,11 @@ def main():
             ctx.set_uniforms(us[g % n_seq])
             ctx.render_tiles_async(variant, rank, world, my_tiles[b].data_ptr(), streams[0])
             host_list = [torch.empty(my_tiles[b].numel()) for _ in range(world)] if rank == 0 else None
+            torch.cuda.synchronize()  # (the render is on the context's stream, the copy below on torch's: nothing else orders them)
             dist.gather(my_tiles[b].cpu(), host_list, dst=0)
             if rank == 0:
                 gathered[b].copy_(torch.stack(host_list))
+                torch.cuda.synchronize()  # (as above: torch's copy, then the context's stream)
                 ctx.unpack_tiles_async(gathered[b].data_ptr(), world, frames[b].data_ptr(), streams[0])
                 last_single[b] = g % n_seq
             g += 1

@@ -279,3 +279,43 @@ def test_measured_kernel_choice_can_be_switched_off(monkeypatch):
             vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
             ran.add(ctx.last_kernel_flavour())
         assert ctx.kernel_choice()[0] == []
+
+
+@pytest.mark.parametrize("variant", [capi.LIGHT, capi.BASIC, capi.VOLUME_MASK])
+@pytest.mark.parametrize("flavour", [17, 16])
+def test_rank_shares_through_the_two_steps_ahead_kernel(variant, flavour):
+    """A rank's share of the tiles (packed, tile t -> rank t mod world) marched by the persistent kernel: the tiles of every rank,
+    un-permuted, are the single-GPU frame bit for bit and the counts add up -- world 2, 3 and 8, a ragged viewport (tiles that
+    hang over both edges), a viewport of one tile, launch after launch on one context (the queue heads), and several frames per
+    launch.  (The measured choice keeps this kernel for batched shares: bench.py's multi-rank legs.)"""
+    n = 24
+    step, count = hr.stepping_params(n, n, n)
+    if variant == capi.VOLUME_MASK:
+        vols, tfs = composite_scene(n, 5)
+    else:
+        vols, tfs = vt.scene(variant, n=n)
+    for W, H in ((200, 150), (1920, 1080), (64, 64)):
+        u = hr.make_uniforms(W, H, steps_count=count, step_size=step, distance=1.0)
+        with capi.Context(W, H, 0) as ctx:
+            ctx.set_kernel_flavour(6)
+            full, _, n_full = vt.gpu_render(ctx, variant, u, vols, tfs)
+            ctx.set_kernel_flavour(flavour)
+            tx, ty = (W + 63) // 64, (H + 63) // 64
+            for world in (2, 3, 8):
+                frame = np.zeros_like(full)
+                total = 0
+                for rank in range(world):
+                    ctx.render_tiles(variant, rank, world)
+                    cnt = ctx.tile_count(rank, world)
+                    if cnt:
+                        assert ctx.last_kernel_flavour() == (17 if variant == capi.VOLUME_MASK else flavour)
+                    tl, ns = ctx.download_tiles(cnt)
+                    total += ns
+                    for i in range(cnt):
+                        t = rank + i * world
+                        y0, x0 = (t // tx) * 64, (t % tx) * 64
+                        h, w = min(64, H - y0), min(64, W - x0)
+                        frame[y0:y0 + h, x0:x0 + w] = tl[i, :h, :w]
+                        assert not tl[i, h:, :].any() and not tl[i, :, w:].any()
+                assert np.array_equal(vt.bits(frame), vt.bits(full)), (W, H, world)
+                assert total == n_full, (W, H, world)
