@@ -71,6 +71,7 @@ KERNEL_OF_FLAVOUR = {1: "march_kernel (no skipping)", 2: "march_wtb_light_kernel
                      10: "march_dp_kernel (4 lanes per ray, pipelined)", 11: "march_dp_kernel (2 lanes per ray, pipelined)",
                      12: "march_pw_kernel (persistent wavefronts, TF slot 0 in LDS)",
                      13: "march_pw_kernel (persistent wavefronts, TF slot 0 in LDS, corner loads pipelined)",
+                     18: "march_kernel (one lane per ray, slot arithmetic from LDS tables)",
                      16: "march_p2_kernel (persistent wavefronts, indexed corner loads two steps ahead, slot tables in LDS, no skipping)",
                      17: "march_p2_kernel (persistent wavefronts, indexed corner loads two steps ahead, slot tables in LDS, skipping decided ahead of the loads)"}
 

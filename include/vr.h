@@ -317,8 +317,8 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *      frames per launch, vr_hint_frames_in_flight, volume / table uploads, arithmetic, layout; the trial re-opens when the
  *      longest ray chain has moved by a quarter.  Candidates: the prior's pick (exact skipping; whole one-at-a-time frames of
  *      the lit / unlit shader and the composite: 17, or 16 with nothing to skip; else lanes per ray from the launch size, the
- *      frames in flight and the chain length of an earlier launch), 17 / 16, 6, and 10 / 11 (launches that leave the machine part
- *      empty) or 12.  vr_kernel_choice reports what was measured.  VR_EXP_TUNE=0 in the environment: the prior alone.
+ *      frames in flight and the chain length of an earlier launch), 17 / 16, 6, 18, and 10 / 11 (launches that leave the machine
+ *      part empty) or 12.  vr_kernel_choice reports what was measured.  VR_EXP_TUNE=0 in the environment: the prior alone.
  *   1  one lane per ray, no empty-space skipping (every composited sample is fetched)
  *   2 / 3  LDS wave tiles without / with skipping (lit shader only; others fall back to 1 / 6)
  *   4  skipping + closed-form leaping (f32 accumulation as integer arithmetic on the bit patterns)
@@ -340,6 +340,10 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *      per-brick mask record; volumes of 4 GiB and more through a window of z-slabs of bricks that follows the packet; launches of
  *      several frames take (frame, packet) items from the one queue.  Needs one table resolution <= 8190 and the bricked copy
  *      (vr_set_volume_layout(0)); else 13 / 12, or 6 for launches of several frames
+ *   18  the one-lane kernel (6) with the slot arithmetic of volume 0's cells from per-axis tables in its workgroup's LDS (the
+ *      clamp-to-edge texel pair of a coordinate is one ds_read2_b32; filled per workgroup, by the workgroups that can hit the box);
+ *      the shaders that sample one volume (lit, unlit, in-shader gradient) on the bricked copy, launches of any number of frames;
+ *      else it runs as 6
  *   14  (experimental build) lanes per ray chosen PER PACKET (csrc/vr_mixed.h): packets whose longest ray chain in an earlier
  *      launch of the same shape reached 75 % of that launch's longest are marched as two half packets with two lanes per ray,
  *      the rest with one; one-frame launches of the shaders that have a depth-parallel form
@@ -350,7 +354,7 @@ int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
  * milliseconds per launch measured for each (0 = its trial has not been evaluated yet) and the index of the one kept (-1 = trial
  * running: the prior's pick, flavours[0], runs meanwhile).  Returns the number of candidates (0: nothing launched through the
  * default yet, or the shape has a single eligible form).                                                               */
-int vr_kernel_choice(vr_ctx* ctx, int flavours[4], float ms_per_launch[4], int* chosen);
+int vr_kernel_choice(vr_ctx* ctx, int flavours[6], float ms_per_launch[6], int* chosen);
 
 /* 1 if the library was built with -DVR_EXPERIMENTAL_FLAVOURS=1: the kernel forms that lost every A/B -- flavours 2, 3, 4, 5, 9,
  * 14, 15 and volume layout 2 -- are then compiled in; 0 (the shipped build): vr_set_kernel_flavour / vr_set_volume_layout return

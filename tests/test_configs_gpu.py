@@ -101,7 +101,7 @@ def test_config_flavours_and_tile_partition_agree_at_full_size(workload):
         base, n_base, cov_base, _ = gpu_frame(app)
         assert_frame_equal(base, ref, (workload, 1))
         assert (n_base, cov_base) == (n_ref, cov_ref)
-        for fl in (0, 6, 11, 10, 12, 13, 16, 17):
+        for fl in (0, 6, 11, 10, 12, 13, 16, 17, 18):
             ctx.set_kernel_flavour(fl)
             for rep in range(2 if fl else 5):  # (the default settles on its kernel after a few launches; every one is checked)
                 frag, n_f, cov_f, _ = gpu_frame(app)
@@ -110,6 +110,8 @@ def test_config_flavours_and_tile_partition_agree_at_full_size(workload):
             ran = ctx.last_kernel_flavour()
             if fl in (6, 10, 11, 12):
                 assert ran == fl, (workload, fl, ran)
+            elif fl == 18:
+                assert ran == (18 if vname in ("LIGHT", "BASIC") else 6), (workload, fl, ran)
             elif fl == 13:
                 assert ran == (13 if vname == "LIGHT" else 12) or ran == 13, (workload, fl, ran)
             elif fl == 16:
@@ -170,12 +172,12 @@ def test_c5_16gib_volume_64bit_addressing_vs_oracle():
         # no-skipping kernel and the depth-parallel kernels: same bits, same counts
         # (`frag` has just been compared with the oracle: equality with it is equality with the oracle.  16 / 17: the moving gather
         # window of march_p2_kernel, the volume being four windows long)
-        for fl in (1, 11, 12, 17, 16):
+        for fl in (1, 11, 12, 17, 16, 18):
             ctx.set_kernel_flavour(fl)
             f2, n2, cov2, _ = gpu_frame(app)
             assert np.array_equal(vt.bits(f2), vt.bits(frag)), fl
             assert (n2, cov2) == (n_gpu, cov_gpu), fl
-            assert ctx.last_kernel_flavour() == fl, (fl, ctx.last_kernel_flavour())
+            assert ctx.last_kernel_flavour() == fl, (fl, ctx.last_kernel_flavour())  # (18 on C5: 64-bit addresses from the tables' slots)
         ctx.set_kernel_flavour(0)
         # one rank's share of an 8-GPU partition = the same pixels of the full frame
         world = 8

@@ -319,3 +319,64 @@ def test_rank_shares_through_the_two_steps_ahead_kernel(variant, flavour):
                         assert not tl[i, h:, :].any() and not tl[i, :, w:].any()
                 assert np.array_equal(vt.bits(frame), vt.bits(full)), (W, H, world)
                 assert total == n_full, (W, H, world)
+
+
+# ---- flavour 18: march_kernel with its slot arithmetic from LDS tables (csrc/vr_kernels.h: make_cell_lut) ---------------------------
+@pytest.mark.parametrize("variant", [capi.LIGHT, capi.BASIC, capi.LIGHT_INSHADER])
+def test_slot_tables_in_the_one_lane_kernel(variant):
+    """Flavour 18 = flavour 6 with make_cell() reading the clamp-to-edge texel pairs' slot terms from per-axis tables in the
+    workgroup's LDS: frames bit-equal to the oracle, per-packet records equal to flavour 6's; volumes whose sides are not multiples
+    of the brick edge and differ per axis (the tables' lengths and offsets), cameras that see the volume's faces and edges (the
+    clamped pairs at t = -1 and t = n - 1), clip boxes, jitter, one step; the x-fastest layout has no tables (runs as 6); several
+    frames per launch; other shaders run as 6."""
+    W, H = 200, 120
+    rng = np.random.default_rng(5)
+    for dims in ((24, 24, 24), (37, 18, 29), (7, 50, 13)):
+        nx, ny, nz = dims
+        raw = (rng.integers(0, 3000, size=(nz, ny, nx)) * (rng.random((nz, ny, nx)) > 0.6)).astype(np.uint16)
+        vol = ob.normalize_data(hr.raw_to_vec4(raw))
+        if variant != capi.BASIC:
+            vol = ob.precompute_gradient(vol)
+        tf = zero_prefix_tf(64, 6, top=0.7)
+        step, count = hr.stepping_params(nx, ny, nz)
+        with capi.Context(W, H, 0) as ctx:
+            for kw in CAMERAS[:9]:
+                args = dict(steps_count=count, step_size=step)
+                args.update(kw)
+                u = hr.make_uniforms(W, H, **args)
+                recs = {}
+                for fl in (6, 18):
+                    ctx.set_kernel_flavour(fl)
+                    check(ctx, variant, u, [vol], [tf], W, H)
+                    assert ctx.last_kernel_flavour() == fl
+                    recs[fl] = ctx.block_trace().astype(np.uint64)
+                assert np.array_equal(recs[6][:, :3], recs[18][:, :3]), (dims, kw)
+            ctx.set_volume_layout(3)   # the reference's x-fastest arrays: no bricked copy to build tables for
+            ctx.set_kernel_flavour(18)
+            check(ctx, variant, hr.make_uniforms(W, H, steps_count=count, step_size=step), [vol], [tf], W, H)
+            assert ctx.last_kernel_flavour() == 6
+            ctx.set_volume_layout(0)
+    # several frames per launch, and a shader with two volumes (falls back)
+    n = 24
+    step, count = hr.stepping_params(n, n, n)
+    us = _batch_uniforms(136, 100, count, step)
+    vols, tfs = vt.scene(variant, n=n)
+    with capi.Context(136, 100, 0) as ctx:
+        ctx.set_kernel_flavour(6)
+        refs = [vt.gpu_render(ctx, variant, u, vols, tfs) for u in us]
+        others = [capi.Context(136, 100, 0) for _ in range(4)]
+        try:
+            ctx.set_kernel_flavour(18)
+            ctx.render_batch_async(variant, [vt.to_capi_uniforms(u) for u in us], [o.frame_device_ptr() for o in others], ctx.stream(0))
+            assert ctx.counters()[0] == refs[3][2] and ctx.last_kernel_flavour() == 18
+            ctx.resize(136, 100)
+            for o, ref in zip(others, refs):
+                got, _, _ = o.download()
+                assert np.array_equal(vt.bits(got), vt.bits(ref[0]))
+        finally:
+            for o in others:
+                o.close()
+        v2, t2 = vt.scene(capi.MULTI_CTRT, n=n)
+        ctx.set_kernel_flavour(18)
+        check(ctx, capi.MULTI_CTRT, us[0], v2, t2, 136, 100)
+        assert ctx.last_kernel_flavour() == 6

@@ -233,7 +233,7 @@ def test_skipping_with_hostile_values(ctx):
     tf = zero_prefix_tf(32, 3)
     for variant in (capi.BASIC, capi.LIGHT, capi.LIGHT_INSHADER):
         ref, n_ref, _ = ob.render(variant, u, [v], [tf], W, H, nthreads=8)
-        for flavour in vt.flavours(0, 1, 5, 6, 8, 9, 11, 12, 13, 14, 15, 16, 17):  # every loop form and lanes-per-ray layout
+        for flavour in vt.flavours(0, 1, 5, 6, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18):  # every loop form and lanes-per-ray layout
             ctx.set_kernel_flavour(flavour)
             frag, _, ns = vt.gpu_render(ctx, variant, u, [v], [tf])
             assert same(frag, ref) and ns == n_ref, (variant, flavour)
@@ -248,7 +248,7 @@ def test_skipping_with_hostile_values(ctx):
         for variant in (capi.BASIC, capi.LIGHT):
             ref, n_ref, _ = ob.render(variant, u, [lone], [tf], W, H, nthreads=8)
             assert np.isnan(ref).any()
-            for flavour in vt.flavours(0, 6, 11, 12, 13, 15, 16, 17):
+            for flavour in vt.flavours(0, 6, 11, 12, 13, 15, 16, 17, 18):
                 ctx.set_kernel_flavour(flavour)
                 frag, _, ns = vt.gpu_render(ctx, variant, u, [lone], [tf])
                 assert same(frag, ref) and ns == n_ref, (bad, where, variant, flavour)
@@ -368,7 +368,7 @@ def test_skipping_on_a_mostly_empty_volume(ctx):
                 assert ctx.counters()[2] < 0.5 * ns
 
 
-@pytest.mark.parametrize("flavour", vt.flavours(4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17))
+@pytest.mark.parametrize("flavour", vt.flavours(4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18))
 def test_exact_leaping_flavour(ctx, flavour):
     """Every way of getting through empty space and every lanes-per-ray layout must reproduce the step-by-step
     accumulation bit for bit (frames AND sample counts): 5 single steps, 6 wave-uniform runs of plain additions,
@@ -393,7 +393,7 @@ def test_exact_leaping_flavour(ctx, flavour):
                 kw.update(extra)
                 u = hr.make_uniforms(W, H, **kw)
                 for variant in (capi.BASIC, capi.LIGHT, capi.THREE_FILES, capi.LIGHT_INSHADER):
-                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6, 12, 13, 15, 16, 17):
+                    if variant == capi.LIGHT_INSHADER and flavour not in (4, 5, 6, 12, 13, 15, 16, 17, 18):
                         continue  # one-lane kernel only: the other flavours resolve to 6
                     vols = [v] if variant != capi.THREE_FILES else [v, vt.dose_volume()]
                     tfs = [tf] if variant != capi.THREE_FILES else [tf, vt.scene(capi.THREE_FILES, n=8)[1][1]]
@@ -406,7 +406,7 @@ def test_exact_leaping_flavour(ctx, flavour):
         ctx.set_kernel_flavour(0)
 
 
-@pytest.mark.parametrize("flavour", vt.flavours(6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17))
+@pytest.mark.parametrize("flavour", vt.flavours(6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18))
 @pytest.mark.parametrize("variant", range(8))
 def test_every_variant_every_layout(ctx, variant, flavour):
     """The default picks the lanes per ray from the launch size (small test frames always get four); every layout is
@@ -434,7 +434,7 @@ def test_default_layout_follows_launch_size(ctx):
     ctx.resize(W, H)
     try:
         frames = []
-        for fl in vt.flavours(0, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17):
+        for fl in vt.flavours(0, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17, 18):
             ctx.set_kernel_flavour(fl)
             frag, _, n = vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
             frames.append((vt.bits(frag), n))
@@ -508,7 +508,7 @@ def test_two_frames_in_flight_on_two_streams(ctx):
         ctx.render(capi.LIGHT)
         ref2, _, n2 = ctx.download()
         assert n1 != n2
-        for fl in (0, 6, 10, 17, 16):
+        for fl in (0, 6, 10, 17, 16, 18):
             ctx.set_kernel_flavour(fl)
             for k in range(8):  # same uniforms for a whole burst: they are read when the launch is enqueued
                 ctx.render_async(capi.LIGHT, bufs[k & 1].value, streams[k & 1].value)
@@ -674,7 +674,7 @@ def test_fused_every_variant_every_loop_form(fused, variant):
     W, H = 70, 45
     vols, tfs = vt.scene(variant, n=24)
     step, count = hr.stepping_params(24, 24, 24)
-    for fl in vt.flavours(0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17):
+    for fl in vt.flavours(0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18):
         fused.set_kernel_flavour(fl)
         for kw in (dict(), dict(clip_x=(0.2, 0.1), clip_z=(0.0, 0.3)), dict(toggles=(1, 1, 0, 0), yaw=2.0, pitch=-0.4),
                    dict(distance=0.7, yaw=1.0)):
@@ -694,7 +694,7 @@ def test_fused_empty_space_skipping_is_exact(fused, variant, zeros):
     for cam in (dict(yaw=0.9, pitch=-0.3), dict(yaw=-2.1, pitch=0.6, distance=0.85)):
         u = hr.make_uniforms(W, H, steps_count=count, step_size=step, **cam)
         outs = []
-        for fl in vt.flavours(0, 1, 5, 11, 12, 13, 15, 16, 17):
+        for fl in vt.flavours(0, 1, 5, 11, 12, 13, 15, 16, 17, 18):
             fused.set_kernel_flavour(fl)
             frag, n_s = check(fused, variant, u, vols, tfs, W, H)
             outs.append((vt.bits(frag), n_s))
@@ -796,7 +796,7 @@ def _batch_uniforms(W, H, count, step):
 
 
 @pytest.mark.parametrize("variant", [capi.BASIC, capi.LIGHT, capi.VOLUME_MASK, capi.MULTI_CTRT])
-@pytest.mark.parametrize("flavour", [0, 1, 6, 10, 11, 16, 17])
+@pytest.mark.parametrize("flavour", [0, 1, 6, 10, 11, 16, 17, 18])
 def test_frames_of_one_launch_equal_single_renders(ctx, variant, flavour):
     """vr_render_batch_async: n = 1..4 frames of the same scene marched by ONE grid, each with its own uniforms and output
     buffer, are bit-equal to vr_render with those uniforms (which the other tests pin to the oracle); the counters reported

@@ -326,7 +326,7 @@ class Context:
 
     def kernel_choice(self):
         """(candidate flavours, ms per launch measured for each, index of the one kept or -1) of the default's measured choice."""
-        fl, ms, ch = (C.c_int * 4)(), (C.c_float * 4)(), C.c_int(-1)
+        fl, ms, ch = (C.c_int * 6)(), (C.c_float * 6)(), C.c_int(-1)
         n = self.lib.vr_kernel_choice(self.h, fl, ms, C.byref(ch))
         if n < 0:
             self._chk(n)

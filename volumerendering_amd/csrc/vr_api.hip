@@ -114,13 +114,13 @@ struct vr_ctx {
     struct Tune {
         unsigned long long key = 0;   // shader, share, viewport, frames per launch, frames in flight, scene epoch, arithmetic, layout (0 = free)
         unsigned long long shape = 0; // ... the same without the scene's epochs: a new scene starts from what the last one of this shape kept
-        int n = 0, cand[4] = {};      // the eligible flavours; cand[0] = the prior's pick (what runs while nothing is known)
+        int n = 0, cand[6] = {};      // the eligible flavours; cand[0] = the prior's pick (what runs while nothing is known)
         int cur = 0, issued = 0;      // candidate on trial, launches it has had
         int per = 3, settle = 4;      // launches per candidate; launches before the trial starts (no launch order exists yet)
-        long long launch0[4] = {};    // ring.head of each candidate's first trial launch
+        long long launch0[6] = {};    // ring.head of each candidate's first trial launch
         int choice = -1;              // index into cand of the kernel kept (-1 = trial running)
         unsigned chain_ref = 0;       // longest ray chain + 1 when it was chosen: the trial re-opens when that has moved by a quarter
-        float cost[4] = {};           // ms per launch measured (0 = no data)
+        float cost[6] = {};           // ms per launch measured (0 = no data)
         unsigned long long used = 0;  // (least recently used slot is recycled)
     } tune[8];
     unsigned long long tune_clock = 0;
@@ -343,14 +343,14 @@ int tune_pick(vr_ctx* c, unsigned long long key, unsigned long long shape, const
         e.n = 0;
         e.cand[e.n++] = first;
         for (int i = 0; i < n; ++i)
-            if (cand[i] != first && e.n < 4) e.cand[e.n++] = cand[i];
+            if (cand[i] != first && e.n < 6) e.cand[e.n++] = cand[i];
         e.cur = 0;
         e.issued = 0;
         e.per = in_flight > 1 ? 3 * in_flight + 2 : 3;
         e.settle = in_flight + 3;
         e.choice = -1;
         e.chain_ref = 0;
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 6; ++i) {
             e.cost[i] = 0.0f;
             e.launch0[i] = -1;
         }
@@ -581,6 +581,17 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         p2_lds = (unsigned)lds;
     }
     if ((fl == 16 || fl == 17) && !p2_ok) fl = n_frames != 1 ? 6 : (fl == 16 ? 13 : 12);
+    // 18: march_kernel with the slot tables of volume 0 in its workgroup's LDS (make_cell_lut): the shaders that sample ONE volume, the
+    // bricked copy with 32-bit slots (bricks of rows and slabs below 2^24 slots as above); else 6
+    bool lut_ok = (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC || variant == VR_VARIANT_LIGHT_INSHADER) && c->layout_mode == 0 &&
+                  c->vol_bricked[0] && c->vol_bdens[0];
+    unsigned lut_lds = 0;
+    if (lut_ok) {
+        const size_t nbx = ((unsigned)c->vol[0].nx + kVbM) >> kVbS, nby = ((unsigned)c->vol[0].ny + kVbM) >> kVbS, nbz = ((unsigned)c->vol[0].nz + kVbM) >> kVbS;
+        lut_lds = (unsigned)(((size_t)c->vol[0].nx + c->vol[0].ny + c->vol[0].nz + 6) * 4);
+        lut_ok = nbx * nby * nbz * kVbN <= 0xFFFFFFFFull && lut_lds <= 32u * 1024u;
+    }
+    if (fl == 18 && !lut_ok) fl = 6;
     if (fl == 16 && variant == VR_VARIANT_VOLUME_MASK) fl = 17;  // (the composite's form is the skipping one: its mask records)
     // LDS tiles (15; vr_lt.h): the lit shader, launches of one frame
     if (fl == 15 && (n_frames != 1 || variant != VR_VARIANT_LIGHT)) fl = 6;
@@ -589,7 +600,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     // the illustrative shader's opacity reads the accumulated alpha: its steps cannot be sampled side by side
     if (variant == VR_VARIANT_ILLUSTRATIVE && (fl == 7 || fl == 8 || fl == 10 || fl == 11)) fl = 6;
     // the in-shader gradient variant (seven density fetches per sample) exists as the one-lane kernel only
-    if (variant == VR_VARIANT_LIGHT_INSHADER && fl != 1 && fl != 4 && fl != 5 && fl != 12 && fl != 13) fl = 6;
+    if (variant == VR_VARIANT_LIGHT_INSHADER && fl != 1 && fl != 4 && fl != 5 && fl != 12 && fl != 13 && fl != 18) fl = 6;
     c->last_flavour = fl;
     bool can_skip = skip_variant && fl != 1 && fl != 2 && c->vol_bricks[sv] && c->tf_zero_prefix[0] >= 0 &&
                     c->tf_color_finite[0];
@@ -691,15 +702,16 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     // own records stays.  Candidates: the prior; the two-steps-ahead kernel; the one-lane kernel; the depth-parallel kernel (launches
     // that leave the machine part empty) or the persistent kernel without the pipeline (the longest chains).
     if (auto_choice && c->tune_mode && c->pw_policy) {
-        int cand[4], n = 0;
+        int cand[6], n = 0;
         auto add = [&](int f) {
             for (int i = 0; i < n; ++i)
                 if (cand[i] == f) return;
-            if (n < 4) cand[n++] = f;
+            if (n < 6) cand[n++] = f;
         };
         add(fl);
         if (p2_ok && p2_variant) add((nothing_to_skip && variant != VR_VARIANT_VOLUME_MASK) || !can_skip ? 16 : 17);
         add(6);
+        if (lut_ok && lut_lds <= 8u * 1024u) add(18);  // (the one-lane kernel with its slot arithmetic from LDS tables; larger tables cost it wavefronts per CU: C5 4.2 vs 3.4 ms)
         const bool dp_variant = variant != VR_VARIANT_ILLUSTRATIVE && variant != VR_VARIANT_LIGHT_INSHADER;
         if (!whole_frame && dp_variant) add((double)px_all * c->frames_in_flight * n_frames / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 2.0 ? 11 : 10);
         else if (n_frames == 1 && (variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC)) add(12);
@@ -714,6 +726,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     c->last_flavour = fl;
 
     if (c->layout_mode == 0 && fl != 2 && fl != 3) use_bricked();
+    if (fl == 18 && P.vol[0].bricked) P.vol[0].lut = 1;  // (march_kernel fills the tables; every fetch of volume 0 goes through them)
     for (int i = 0; i < nvol; ++i)  // (a bricked copy is padded to whole bricks: a volume just below 4 GiB may cross the line)
         if (P.vol[i].bricked && (size_t)P.vol[i].brick_slab * (((unsigned)P.vol[i].nz + kVbM) >> kVbS) * 16 > 0xFFFFFFFFull) off32 = false;
 
@@ -839,7 +852,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             L.pw_p2 = false;
             L.pw_p2_skip = false;
             L.pw_p2_win = false;
-            L.lds_bytes = 0;
+            L.lds_bytes = (fl == 18 && P.vol[0].lut) ? lut_lds : 0u;
             L.queue = PwQueue{nullptr, 0u, 0u, 0u};
             L.mixed_items = nullptr;
             L.n_logical = 0;
@@ -1232,7 +1245,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_FLAVOUR")) {
         const int f = atoi(e);
-        if (f >= 0 && f <= 17 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9 || f == 14 || f == 15))) c->default_flavour = f;
+        if (f >= 0 && f <= 18 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9 || f == 14 || f == 15))) c->default_flavour = f;
     }
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
@@ -1907,7 +1920,7 @@ int vr_volume_layout(vr_ctx* c, int slot, int* flags)
     return VR_OK;
 }
 
-int vr_kernel_choice(vr_ctx* c, int flavours[4], float ms_per_launch[4], int* chosen)
+int vr_kernel_choice(vr_ctx* c, int flavours[6], float ms_per_launch[6], int* chosen)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     const vr_ctx::Tune* t = nullptr;
@@ -1915,7 +1928,7 @@ int vr_kernel_choice(vr_ctx* c, int flavours[4], float ms_per_launch[4], int* ch
         if (e.key != 0 && e.used != 0 && (!t || e.used > t->used)) t = &e;
     if (chosen) *chosen = t ? t->choice : -1;
     if (!t) return 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 6; ++i) {
         if (flavours) flavours[i] = i < t->n ? t->cand[i] : 0;
         if (ms_per_launch) ms_per_launch[i] = i < t->n ? t->cost[i] : 0.0f;
     }
@@ -1925,7 +1938,7 @@ int vr_kernel_choice(vr_ctx* c, int flavours[4], float ms_per_launch[4], int* ch
 int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
-    if (flavour < 0 || flavour > 17) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
+    if (flavour < 0 || flavour > 18) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
     if (!VR_EXPERIMENTAL_FLAVOURS && (flavour == 2 || flavour == 3 || flavour == 4 || flavour == 5 || flavour == 9 || flavour == 14 || flavour == 15))
         return fail(c, VR_ERR_UNSUPPORTED, "vr_set_kernel_flavour: flavours 2, 3, 4, 5, 9, 14 and 15 are compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
     c->flavour = flavour;

@@ -56,6 +56,11 @@ struct DevVolume {
     int bricked;
     unsigned brick_row, brick_slab;  // voxels per row of bricks (ceil(nx / 4) * 64) and per slab of bricks (* ceil(ny / 4))
     unsigned data_bytes;             // size of `data` (the range of the kernels' buffer loads; volumes below 4 GiB)
+    // 1: the workgroup's dynamic LDS holds this (bricked) volume's per-axis SLOT TABLES -- entry e (0 .. n + 1) of an axis = the slot
+    // term of texel clamp(e - 1, 0, n - 1), the three axes one after the other -- and make_cell() reads the clamp-to-edge texel
+    // pair of a coordinate t (-1 .. n - 1) as the entries t + 1, t + 2 with one ds_read2_b32 instead of computing clamps, shifts,
+    // masks and multiplies (flavour 18: march_kernel fills the tables per workgroup; 0 elsewhere)
+    int lut;
 };
 
 // Both tables are stored with their first and their last texel repeated once at either end: table[k] is at [k+1].

@@ -224,6 +224,16 @@ __device__ inline float pow_rep(float x, float y)
 }
 
 // ------------------------------------------------------------------------------------------------ sampling
+// The workgroup's dynamic LDS (persistent kernels: the merged transfer function of slot 0 first, vr_pw.h / vr_p2.h; flavour 18: the
+// slot tables of volume 0, below).
+extern __shared__ float4 vr_lds_tf[];
+// Indexed buffer loads (buffer_load ... idxen: the VGPR holds a RECORD index, the descriptor its stride): not a clang builtin yet,
+// so the intrinsics by their LLVM names -- the compiler tracks them like the raw form.  Same rate as a raw load of the byte offset
+// (tools/ubench/struct_buffer.hip) without the shift; index x stride wraps at 32 bits, so for buffers below 4 GiB only.
+typedef unsigned vr_u4i __attribute__((ext_vector_type(4)));
+extern "C" __device__ vr_u4i vr_struct_load_b128(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.ptr.buffer.load.v4i32");
+extern "C" __device__ unsigned vr_struct_load_b32(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.ptr.buffer.load.i32");
+
 struct Cell {  // the 2x2x2 texel cell of one linear 3-D fetch
     unsigned o000, o100, o010, o110, o001, o101, o011, o111;  // voxel indices
     float fx, fy, fz;
@@ -237,8 +247,51 @@ __device__ __forceinline__ void texel_step(float x0, int n, int& i0, bool& next)
     i0 = max(t, 0);
     next = (unsigned)t < (unsigned)(n - 1);
 }
+// Slot tables in LDS (DevVolume::lut): all threads of the workgroup fill them, the caller puts a barrier behind.
+__device__ __forceinline__ void lut_fill(const DevVolume& v)
+{
+    unsigned* tab = reinterpret_cast<unsigned*>(vr_lds_tf);
+    for (int e = (int)threadIdx.x; e < v.nx + 2; e += (int)blockDim.x) {
+        const unsigned i = (unsigned)min(max(e - 1, 0), v.nx - 1);
+        tab[e] = (i >> kVbS) * kVbN + (i & kVbM);
+    }
+    tab += v.nx + 2;
+    for (int e = (int)threadIdx.x; e < v.ny + 2; e += (int)blockDim.x) {
+        const unsigned j = (unsigned)min(max(e - 1, 0), v.ny - 1);
+        tab[e] = (j >> kVbS) * v.brick_row + ((j & kVbM) << kVbS);
+    }
+    tab += v.ny + 2;
+    for (int e = (int)threadIdx.x; e < v.nz + 2; e += (int)blockDim.x) {
+        const unsigned k = (unsigned)min(max(e - 1, 0), v.nz - 1);
+        tab[e] = (k >> kVbS) * v.brick_slab + ((k & kVbM) << (2u * kVbS));
+    }
+}
+// make_cell through the tables: the clamp to [-1, n - 1] selects the same texel pair as texel_pair() for ANY value of the floored
+// coordinate (saturated conversions, NaN -> 0), so the eight slots are make_cell's.
+__device__ __forceinline__ Cell make_cell_lut(const DevVolume& v, f3 p)
+{
+    const float x = mad(p.x, (float)v.nx, -0.5f), y = mad(p.y, (float)v.ny, -0.5f), z = mad(p.z, (float)v.nz, -0.5f);
+    const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+    Cell c;
+    c.fx = x - x0;
+    c.fy = y - y0;
+    c.fz = z - z0;
+    const int tx = min(max((int)x0, -1), v.nx - 1), ty = min(max((int)y0, -1), v.ny - 1), tz = min(max((int)z0, -1), v.nz - 1);
+    const unsigned* tab = reinterpret_cast<const unsigned*>(vr_lds_tf);
+    const unsigned* tx_ = tab + (tx + 1);
+    const unsigned* ty_ = tab + (v.nx + 2) + (ty + 1);
+    const unsigned* tz_ = tab + (v.nx + 2) + (v.ny + 2) + (tz + 1);
+    const unsigned ax0 = tx_[0], ax1 = tx_[1], ay0 = ty_[0], ay1 = ty_[1], az0 = tz_[0], az1 = tz_[1];
+    const unsigned r00 = ay0 + az0, r10 = ay1 + az0, r01 = ay0 + az1, r11 = ay1 + az1;
+    c.o000 = r00 + ax0; c.o100 = r00 + ax1;
+    c.o010 = r10 + ax0; c.o110 = r10 + ax1;
+    c.o001 = r01 + ax0; c.o101 = r01 + ax1;
+    c.o011 = r11 + ax0; c.o111 = r11 + ax1;
+    return c;
+}
 __device__ __forceinline__ Cell make_cell(const DevVolume& v, f3 p)
 {
+    if (v.lut) return make_cell_lut(v, p);  // (wave-uniform: flavour 18)
     float x = mad(p.x, (float)v.nx, -0.5f);
     float y = mad(p.y, (float)v.ny, -0.5f);
     float z = mad(p.z, (float)v.nz, -0.5f);
@@ -326,8 +379,9 @@ __device__ __forceinline__ float4 load_voxel(const DevVolume& v, unsigned idx)
 {
 #if VR_BUFFER_LOADS
     if constexpr (OFF32) {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(v.data), 0, (int)v.data_bytes, 0x00020000);
-        const vr_f4 f = __builtin_bit_cast(vr_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx << 4), 0, 0));
+        // (indexed: records of 16 B, the voxel's index in the VGPR -- no shift per corner; round 4)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(v.data), 16, (int)(v.data_bytes >> 4), 0x00020000);
+        const vr_f4 f = __builtin_bit_cast(vr_f4, vr_struct_load_b128(rsrc, (int)idx, 0, 0, 0));
         return make_float4(f.x, f.y, f.z, f.w);
     }
 #endif
@@ -633,7 +687,6 @@ __device__ __forceinline__ TfSample tf_lookup(const DevTF& tf, float d) { return
 // texels their density selects) is two ds_read_b128 instead of four L1 look-ups behind the other wavefronts' corner loads.
 // The host asks for it only when the two tables have one resolution (every scene of the reference until a preset of
 // another size is loaded): one index and one weight, as in tf_fetch.  Same texels, same lerps: the same bits.
-extern __shared__ float4 vr_lds_tf[];
 __device__ __forceinline__ TfFetch tf_fetch_lds(const DevTF& tf, float d)
 {
     const float xo = mad(d, (float)tf.res_o, -0.5f);
@@ -1618,6 +1671,15 @@ __global__ __launch_bounds__(256, VR_LIGHT_WAVES_PER_EU(V, OTF)) void march_kern
     PixelSlot slot = map_pixel(P);
     float4 dst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     unsigned blends = 0, covered = 0, fetched = 0;
+    // flavour 18: the workgroup's slot tables (DevVolume::lut, make_cell_lut) -- only a workgroup one of whose pixels can hit the
+    // box fills them (three quarters of a frame's packets cannot: they end before they would read a table)
+    if (B.frame[0].vol[0].lut) {
+        const bool may_hit = slot.active && slot.px >= P.rect[0] && slot.px <= P.rect[2] && slot.py >= P.rect[1] && slot.py <= P.rect[3];
+        if (__syncthreads_or(may_hit ? 1 : 0)) {
+            lut_fill(B.frame[0].vol[0]);
+            __syncthreads();
+        }
+    }
 
     march_packet<V, OFF32, SKIP, LEAP, OTF, false>(P, slot, dst, blends, covered, fetched);
 

@@ -27,7 +27,7 @@
 namespace VR_KNS {
 
 template <int V, bool OTF = false>
-void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchBatch& B)
+void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, const MarchBatch& B, unsigned lds_bytes = 0)
 {
     constexpr bool kCanSkip = (V == V_BASIC || V == V_LIGHT || V == V_THREE_FILES || V == V_VOLUME_MASK || V == V_LIGHT_INSHADER);
     // launches that carry several frames (MarchBatch) exist for the loop forms the default flavours use: plain and runs
@@ -36,11 +36,11 @@ void launch_variant(bool off32, int leap, dim3 grid, dim3 block, hipStream_t s, 
     do {                                                                                                               \
         if constexpr ((L) == 0 || (L) == 3) {                                                                          \
             if (batch) {                                                                                               \
-                hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF, true>), grid, block, 0, s, B);                       \
+                hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF, true>), grid, block, lds_bytes, s, B);                       \
                 break;                                                                                                 \
             }                                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF, false>), grid, block, 0, s, B);                              \
+        hipLaunchKernelGGL((march_kernel<V, O, S, L, OTF, false>), grid, block, lds_bytes, s, B);                              \
     } while (0)
     if constexpr (kCanSkip) {
         if (B.frame[0].brick_dist) {
@@ -274,19 +274,19 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
             }
         } else
         switch (variant) {
-        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, B); break;
+        case VR_VARIANT_BASIC: launch_variant<V_BASIC>(off32, leap_mode, grid, block, s, B, L.lds_bytes); break;
         case VR_VARIANT_LIGHT:
 #if VR_EXPERIMENTAL_FLAVOURS
             if (otf) launch_variant<V_LIGHT, true>(off32, leap_mode, grid, block, s, B);
             else
 #endif
-                launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, B);
+                launch_variant<V_LIGHT>(off32, leap_mode, grid, block, s, B, L.lds_bytes);
             break;
         case VR_VARIANT_VOLUME_MASK: launch_variant<V_VOLUME_MASK>(off32, leap_mode, grid, block, s, B); break;
         case VR_VARIANT_THREE_FILES: launch_variant<V_THREE_FILES>(off32, leap_mode, grid, block, s, B); break;
         case VR_VARIANT_MULTI_CTRT: launch_variant<V_MULTI_CTRT>(off32, leap_mode, grid, block, s, B); break;
         case VR_VARIANT_ILLUSTRATIVE: launch_variant<V_ILLUSTRATIVE>(off32, leap_mode, grid, block, s, B); break;
-        case VR_VARIANT_LIGHT_INSHADER: launch_variant<V_LIGHT_INSHADER>(off32, leap_mode, grid, block, s, B); break;
+        case VR_VARIANT_LIGHT_INSHADER: launch_variant<V_LIGHT_INSHADER>(off32, leap_mode, grid, block, s, B, L.lds_bytes); break;
         default: launch_variant<V_TF_CALIB>(off32, leap_mode, grid, block, s, B); break;
         }
 }

@@ -25,10 +25,7 @@ using namespace vr;
 
 constexpr int kP2Threads = 768;  // at most 12 wavefronts per CU, 3 per SIMD (two corner buffers are 64 of ~168 VGPRs)
 
-// indexed buffer loads: not a clang builtin yet; the intrinsics by their LLVM names (the compiler tracks them like the raw form)
-typedef unsigned vr_u4i __attribute__((ext_vector_type(4)));
-extern "C" __device__ vr_u4i vr_struct_load_b128(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.ptr.buffer.load.v4i32");
-extern "C" __device__ unsigned vr_struct_load_b32(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.ptr.buffer.load.i32");
+// (indexed buffer loads -- vr_struct_load_b128 / _b32 -- are declared in vr_kernels.h)
 
 // Where the workgroup's LDS holds what (dynamic LDS, vr_lds_tf): the merged transfer function of slot 0, then the three axis
 // tables.  Byte offsets of entry t = -1 of each axis; wave-uniform.
