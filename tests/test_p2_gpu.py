@@ -380,3 +380,33 @@ def test_slot_tables_in_the_one_lane_kernel(variant):
         ctx.set_kernel_flavour(18)
         check(ctx, capi.MULTI_CTRT, us[0], v2, t2, 136, 100)
         assert ctx.last_kernel_flavour() == 6
+
+
+def test_measured_kernel_choice_with_interleaved_shapes():
+    """Two launch shapes taking turns on one context (a rank's share and another rank's: what a one-process driver of several
+    ranks does): each has its own trial, measured on its OWN launches although the other shape's lie in between in the context's
+    record ring; both settle with a cost for every candidate, and every frame is the reference's."""
+    n, W, H = 32, 512, 384
+    vols, tfs = vt.scene(capi.LIGHT, n=n)
+    step, count = hr.stepping_params(n, n, n)
+    u = hr.make_uniforms(W, H, steps_count=count, step_size=step, distance=1.0)
+    with capi.Context(W, H, 0) as ctx:
+        ctx.set_kernel_flavour(6)
+        vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs)
+        refs = []
+        for r in (0, 1):
+            ctx.render_tiles(capi.LIGHT, r, 2)
+            refs.append(ctx.download_tiles(ctx.tile_count(r, 2)))
+        ctx.set_kernel_flavour(0)
+        seen = [set(), set()]
+        for k in range(60):
+            for r in (0, 1):
+                ctx.render_tiles(capi.LIGHT, r, 2)
+                tl, ns = ctx.download_tiles(ctx.tile_count(r, 2))
+                assert ns == refs[r][1] and np.array_equal(vt.bits(tl), vt.bits(refs[r][0])), (k, r)
+                seen[r].add(ctx.last_kernel_flavour())
+                if k == 59:
+                    cands, ms, chosen = ctx.kernel_choice()
+                    assert chosen >= 0 and len(cands) >= 2 and all(m > 0.0 for m in ms), (r, cands, ms, chosen)
+                    assert ms[chosen] <= min(ms) * 1.03
+        assert all(len(s) >= 2 for s in seen)

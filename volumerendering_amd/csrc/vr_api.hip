@@ -117,7 +117,7 @@ struct vr_ctx {
         int n = 0, cand[6] = {};      // the eligible flavours; cand[0] = the prior's pick (what runs while nothing is known)
         int cur = 0, issued = 0;      // candidate on trial, launches it has had
         int per = 3, settle = 4;      // launches per candidate; launches before the trial starts (no launch order exists yet)
-        long long launch0[6] = {};    // ring.head of each candidate's first trial launch
+        long long launch[6][16] = {}; // ring.head of every trial launch of every candidate (other shapes' launches may lie in between)
         int choice = -1;              // index into cand of the kernel kept (-1 = trial running)
         unsigned chain_ref = 0;       // longest ray chain + 1 when it was chosen: the trial re-opens when that has moved by a quarter
         float cost[6] = {};           // ms per launch measured (0 = no data)
@@ -346,13 +346,13 @@ int tune_pick(vr_ctx* c, unsigned long long key, unsigned long long shape, const
             if (cand[i] != first && e.n < 6) e.cand[e.n++] = cand[i];
         e.cur = 0;
         e.issued = 0;
-        e.per = in_flight > 1 ? 3 * in_flight + 2 : 3;
+        e.per = in_flight > 1 ? 3 * in_flight + 2 : 3;  // (<= 14: kStreams is 4)
         e.settle = in_flight + 3;
         e.choice = -1;
         e.chain_ref = 0;
         for (int i = 0; i < 6; ++i) {
             e.cost[i] = 0.0f;
-            e.launch0[i] = -1;
+            for (int q = 0; q < 16; ++q) e.launch[i][q] = -1;
         }
     };
     if (!t) {
@@ -396,7 +396,7 @@ int tune_pick(vr_ctx* c, unsigned long long key, unsigned long long shape, const
     }
     if (t->cur < t->n) {
         const int f = t->cand[t->cur];
-        if (t->issued == 0) t->launch0[t->cur] = c->ring.head;
+        t->launch[t->cur][t->issued] = c->ring.head;  // (the ring slot this launch will record itself in)
         if (++t->issued == t->per) {
             ++t->cur;
             t->issued = 0;
@@ -404,7 +404,7 @@ int tune_pick(vr_ctx* c, unsigned long long key, unsigned long long shape, const
         return f;
     }
     // every candidate has had its turn: are the records in?
-    const long long last = t->launch0[t->n - 1] + t->per - 1;
+    const long long last = t->launch[t->n - 1][t->per - 1];
     if (c->ring.head > last + 64) {  // (a launch of the trial was never measured -- timed with events, or not ordered: keep the prior)
         t->choice = 0;
         t->chain_ref = chain_now;
@@ -412,20 +412,20 @@ int tune_pick(vr_ctx* c, unsigned long long key, unsigned long long shape, const
     }
     for (int i = 0; i < t->n; ++i)
         for (int q = 0; q < t->per; ++q)
-            if (*(volatile unsigned long long*)&c->h_span[(t->launch0[i] + q) % kRing] == 0) return t->cand[0];
+            if (*(volatile unsigned long long*)&c->h_span[t->launch[i][q] % kRing] == 0) return t->cand[0];
     int best = 0;
     for (int i = 0; i < t->n; ++i) {
         double ticks;
         if (in_flight > 1) {
             // (its first `in_flight` launches ran beside the candidate before it, its last ones beside the next: the ends of the
             // launches in between are `in_flight + 2` intervals apart that are this candidate's alone)
-            const unsigned long long e0 = *(volatile unsigned long long*)&c->h_end[(t->launch0[i] + in_flight) % kRing];
-            const unsigned long long e1 = *(volatile unsigned long long*)&c->h_end[(t->launch0[i] + t->per - in_flight) % kRing];
+            const unsigned long long e0 = *(volatile unsigned long long*)&c->h_end[t->launch[i][in_flight] % kRing];
+            const unsigned long long e1 = *(volatile unsigned long long*)&c->h_end[t->launch[i][t->per - in_flight] % kRing];
             ticks = e1 > e0 ? (double)(e1 - e0) / (double)(t->per - 2 * in_flight) : 1.0e18;
         } else {
             ticks = 1.0e18;
             for (int q = 1; q < t->per; ++q) {
-                const double v = (double)*(volatile unsigned long long*)&c->h_span[(t->launch0[i] + q) % kRing];
+                const double v = (double)*(volatile unsigned long long*)&c->h_span[t->launch[i][q] % kRing];
                 ticks = v < ticks ? v : ticks;
             }
         }
