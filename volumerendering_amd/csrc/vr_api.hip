@@ -882,7 +882,8 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 unsigned pw_threads = fl == 17 ? 768u : (fl == 16 ? 512u : 1024u);
                 // (launches in flight: the same shape.  Two workgroups of 6 wavefronts do not share a CU -- the second one's wavefronts
                 // would have to go 1-1-2-2 over the SIMDs where the dispatcher deals 2-2-1-1: measured 0.75 ms per C3 frame, what
-                // one such workgroup per CU takes -- and two of 4 run at 8 wavefronts per CU: 0.63 against 0.54; gpurun_out/r4c)
+                // one such workgroup per CU takes -- and two of 4 run at 8 wavefronts per CU: 0.63 against 0.54; three of 4, the same
+                // 12 wavefronts per CU, take 0.79 ms one frame at a time and 0.62 in flight against 0.55 / 0.51: profiles/r04_p2_launch_shapes.txt)
                 unsigned wg_per_cu = 1;
                 if (p2 && c->p2_threads) pw_threads = c->p2_threads;  // (VR_EXP_P2_THREADS: 64 .. 768)
                 if (p2 && c->p2_wgs) wg_per_cu = c->p2_wgs;           // (VR_EXP_P2_WGS: workgroups per CU the grid is sized for)
