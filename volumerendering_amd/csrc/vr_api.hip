@@ -405,7 +405,9 @@ int tune_pick(vr_ctx* c, unsigned long long key, unsigned long long shape, const
     }
     // every candidate has had its turn: are the records in?
     const long long last = t->launch[t->n - 1][t->per - 1];
-    if (c->ring.head > last + 64) {  // (a launch of the trial was never measured -- timed with events, or not ordered: keep the prior)
+    // (a launch of the trial was never measured -- timed with events, or not ordered -- or so many launches of other shapes ran in
+    // between that the trial's first ring slots are about to be written again: keep the prior)
+    if (c->ring.head > last + 64 || c->ring.head - t->launch[0][0] >= kRing) {
         t->choice = 0;
         t->chain_ref = chain_now;
         return t->cand[0];

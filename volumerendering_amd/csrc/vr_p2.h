@@ -592,7 +592,12 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             // packets' cycles on C3, 3 % of the longest quarter's (-DVR_P2_DEBUG=3, gpurun_out/r4l).  Going back into the pipelined
             // loop when the short rays have retired was built and measured: bit-exact, and SLOWER -- C3 0.525 -> 0.537 ms, C4 0.575
             // -> 0.600 -- the values that then live across both loops cost spills, in the >= 4 GiB kernels between the two exec
-            // writes of p2_issue, where tools/check_exec_regions.py caught them.  Removed.)
+            // writes of p2_issue, where tools/check_exec_regions.py caught them.  Removed.
+            // PARKING the rays that reach their own count (position, world position and step to LDS; the pipelined loop goes on
+            // with the others, this loop takes every parked ray from its own step) was built too: bit-exact, no spill in the
+            // pipelined loop, and slower -- C3 0.553 -> 0.587 ms, C4 0.592 -> 0.636 (tools/experiments/r4u.sh).  A step of this
+            // loop costs about what a pipelined step costs (13 % of the cycles for about as many of the steps): keeping the
+            // pipelined loop going with ever fewer rays saves nothing, and the parked rays' steps here come on top.)
             if (!start) p = pA;
             for (; i < steps_count && vr_ballot(alive) != 0; ++i) {
                 if (alive) {
