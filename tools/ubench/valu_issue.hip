@@ -45,6 +45,16 @@ __global__ __launch_bounds__(1024) void issue_kernel(float* out, unsigned long l
                 if constexpr (KIND == 11) asm volatile("v_add_f32 %0, %2, %0\n\ts_add_u32 %1, %1, 1" : "+v"(a[i].x), "+s"(sa[i]) : "v"(b.x) : "scc");
                 if constexpr (KIND == 12) asm volatile("v_add_f32 %0, %2, %0\n\tv_add_f32 %0, %2, %0\n\ts_add_u32 %1, %1, 1" : "+v"(a[i].x), "+s"(sa[i]) : "v"(b.x) : "scc");
                 if constexpr (KIND == 13) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\ts_and_b64 %2, vcc, exec" : : "v"(a[i].x), "v"(b.x), "s"(sm) : "vcc", "scc");
+                // round 4: what the hazard no-ops of a dependent chain cost (the packed / transcendental / compare-then-select
+                // chains of the shading code: 92 s_nop in march_p2_kernel's loop)
+                if constexpr (KIND == 14) asm volatile("s_nop 0");
+                if constexpr (KIND == 15) asm volatile("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 0" : "+v"(a[0]) : "v"(b), "v"(c));           // ONE chain, per pair
+                if constexpr (KIND == 16) asm volatile("v_fma_f32 %0, %2, %3, %0\n\tv_fma_f32 %1, %2, %3, %1" : "+v"(a[0].x), "+v"(a[0].y) : "v"(b.x), "v"(c.x));  // the same two chains unpacked, per pair
+                if constexpr (KIND == 17) asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n\tv_pk_fma_f32 %1, %2, %3, %1" : "+v"(a[0]), "+v"(a[1]) : "v"(b), "v"(c));  // two packed chains interleaved, per pair
+                if constexpr (KIND == 18) asm volatile("v_cmp_ge_f32 vcc, 0, %0\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[0].x) : "v"(b.x) : "vcc");  // per triple
+                if constexpr (KIND == 19) asm volatile("v_cmp_ge_f32 vcc, 0, %0\n\tv_add_f32 %2, %3, %2\n\tv_add_f32 %4, %3, %4\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[0].x) : "v"(b.x), "v"(a[1].x), "v"(c.x), "v"(a[2].x) : "vcc");  // the no-op's slots filled, per four
+                if constexpr (KIND == 20) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[0].x) : "v"(b.x), "v"(c.x));  // one dependent plain chain
+                if constexpr (KIND == 21) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[0].x) : "v"(b.x));  // (a select as one instruction)
             }
         }
     }
@@ -115,5 +125,13 @@ int main()
     run<11>("v_add+s_add", cus);     // (per PAIR of instructions)
     run<12>("2 v_add+s_add", cus);   // (per TRIPLE)
     run<13>("v_cmp+s_and", cus);     // (per pair)
+    run<14>("s_nop 0", cus);
+    run<15>("pk_fma chain+nop", cus);    // (per pair)
+    run<16>("2 fma chains", cus);        // (per pair)
+    run<17>("2 pk_fma chains", cus);     // (per pair)
+    run<18>("cmp+nop1+cndmask", cus);    // (per triple)
+    run<19>("cmp+2 add+cndmask", cus);   // (per four)
+    run<20>("fma chain", cus);
+    run<21>("v_max chain", cus);
     return 0;
 }
