@@ -410,3 +410,53 @@ def test_measured_kernel_choice_with_interleaved_shapes():
                     assert chosen >= 0 and len(cands) >= 2 and all(m > 0.0 for m in ms), (r, cands, ms, chosen)
                     assert ms[chosen] <= min(ms) * 1.03
         assert all(len(s) >= 2 for s in seen)
+
+
+def blob_volume(n, lo, hi, lit):
+    """Density 0 everywhere but a box of voxels [lo, hi) per axis (0.2 .. 0.9, varying), with its gradient for the lit shader:
+    the active bricks' box is small, off-centre, and may touch the volume's edge."""
+    a = np.zeros((n, n, n), dtype=f32)
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    inside = ((x >= lo[0]) & (x < hi[0]) & (y >= lo[1]) & (y < hi[1]) & (z >= lo[2]) & (z < hi[2]))
+    a[inside] = (0.2 + 0.7 * ((x + 2 * y + 3 * z) % 17) / 16.0).astype(f32)[inside]
+    v = np.zeros((n, n, n, 4), dtype=f32)
+    v[..., 3] = a
+    if lit:
+        v = ob.precompute_gradient(np.ascontiguousarray(v), False)  # (the oracle's PreComputeGradient: VolumeFile.cpp:196-257)
+    return np.ascontiguousarray(v)
+
+
+BLOBS = [((30, 8, 20), (44, 20, 28)),   # small, off-centre
+         ((0, 0, 0), (9, 7, 5)),        # in the volume's first corner (edge bricks: positions beyond them map to them)
+         ((39, 41, 43), (48, 48, 48)),  # in its last corner
+         ((0, 20, 0), (48, 23, 48)),    # a slab across the whole volume
+         ((10, 10, 10), (10, 10, 10))]  # nothing at all: no active brick, every ray passes the volume without a sample
+
+
+@pytest.mark.parametrize("blob", range(len(BLOBS)))
+@pytest.mark.parametrize("variant", [capi.LIGHT, capi.BASIC])
+def test_box_of_the_active_bricks(blob, variant):
+    """The approach loops (march_p2_kernel, march_packet) take a ray through whatever lies outside the box of the active bricks
+    without a look-up, and march_p2_kernel leaves its pipelined loop behind it: frames and counts against the oracle, for boxes that
+    are small, touch the volume's edges, span it, or do not exist, from outside and from inside the volume, with clip planes,
+    variable steps and jitter; the per-packet records of the kernels agree with each other."""
+    n, W, H = 48, 160, 96
+    lo, hi = BLOBS[blob]
+    step, count = hr.stepping_params(n, n, n)
+    vols = [blob_volume(n, lo, hi, variant == capi.LIGHT)]
+    tfs = [zero_prefix_tf(64, 3, top=0.5)]
+    cams = CAMERAS + [dict(yaw=0.3, pitch=0.2, distance=0.15), dict(yaw=-1.2, pitch=-0.9, distance=0.3), dict(yaw=1.5707963, pitch=0.0, distance=1.0)]
+    with capi.Context(W, H, 0) as ctx:
+        for kw in cams:
+            args = dict(steps_count=count, step_size=step)
+            args.update(kw)
+            u = hr.make_uniforms(W, H, **args)
+            recs = {}
+            for fl in (1, 6, 17, 12):
+                ctx.set_kernel_flavour(fl)
+                check(ctx, variant, u, vols, tfs, W, H)
+                recs[fl] = ctx.block_trace().astype(np.uint64)
+            assert ctx.last_kernel_flavour() == 12
+            for fl in (17, 12):
+                assert np.array_equal(recs[6][:, :3], recs[fl][:, :3]), (kw, fl)
+            assert np.array_equal(recs[6][:, :2], recs[1][:, :2]), kw  # (1 fetches every in-box sample: its third word differs)

@@ -89,6 +89,21 @@ def main():
             print(f"[loop counters] {name}: n {sel.sum()}  median duration {np.median(dur[sel]):.0f} us  trips {np.median(trips[sel]):.0f}  sampled steps {np.median(smp[sel]):.0f}"
                   f"  shaded steps {np.median(shd[sel]):.0f}  jumps {np.median(jmp[sel]):.0f}  chain {np.median(crit[sel]):.0f}"
                   f"  us per trip {np.median(dur[sel] / np.maximum(1, trips[sel])):.2f}")
+        # what a step slot costs by kind: least squares over the sampling packets that start while the machine is full
+        # (duration = a x shaded slots + b x sampled-but-not-shaded + c x idle slots + d x jumps + e)
+        idle = 2 * trips.astype(np.float64) - smp
+        st = (t0 - base) / 100.0
+        mid = busy & (st > 0.05 * span) & (st < 0.6 * span) & (trips < 0xfff)
+        if mid.sum() > 50:
+            A = np.stack([shd[mid], (smp - shd)[mid], idle[mid], jmp[mid], np.ones(mid.sum())], axis=1).astype(np.float64)
+            coef, *_ = np.linalg.lstsq(A, dur[mid].astype(np.float64), rcond=None)
+            print(f"[slot costs] {mid.sum()} packets started at 5-60 % of the span: us per shaded slot {coef[0]:.3f}, sampled not shaded {coef[1]:.3f}, "
+                  f"idle slot {coef[2]:.3f}, jump {coef[3]:.3f}, per packet {coef[4]:.1f}")
+        airp = (trips > 0) & ~busy
+        print(f"[packet time] packets with sampled slots {busy.sum()}: {dur[busy].sum() / 1e3:.1f} ms of wavefront time; in the pipelined loop without one {airp.sum()}: "
+              f"{dur[airp].sum() / 1e3:.1f} ms (trips {trips[airp].sum()}, jumps {jmp[airp].sum()}); the rest {(~busy & ~airp).sum()}: {dur[~busy & ~airp].sum() / 1e3:.1f} ms")
+        print(f"[slot totals] sampling packets {busy.sum()}: trips {trips[busy].sum()}  slots {2 * trips[busy].sum()}  sampled {smp[busy].sum()}  shaded {shd[busy].sum()}  "
+              f"idle {int(idle[busy].sum())} ({100 * idle[busy].sum() / max(1, 2 * trips[busy].sum()):.1f} %)  jumps {jmp[busy].sum()}")
     if os.environ.get("VR_P2_DEBUG") == "2":  # (-DVR_P2_DEBUG=2: the covered word holds wait cycles / 64)
         c = tr[:, 1]
         wc, wb, lp = (c & 0xfffff) * 64.0, ((c >> 20) & 0xfffff) * 64.0, ((c >> 40) & 0xffffff) * 64.0

@@ -1,0 +1,30 @@
+#!/bin/bash
+# round 4: distance field capped at 128 bricks instead of 16, march_p2_kernel's jumps at 1024 steps instead of 64
+# (each jump is a dependent byte fetch: the air-only packets of C3 take 22 % of the wavefront time in 9 jumps each)
+O=gpurun_out/r4w
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_p2_gpu.py tests/test_configs_gpu.py tests/test_parity_gpu.py -x -q -m gpu > $O/tests.txt 2>&1 || { tail -30 $O/tests.txt; exit 1; }
+tail -2 $O/tests.txt
+B="python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-regimes --no-live-pmc --turn-frames 0 --settle 0"
+run() {  # tag
+  timeout -k 10 300 $B --flavour 17 > $O/c3_f17_$1.json 2> $O/c3_f17_$1.err || exit 1
+  timeout -k 10 300 $B --flavour 17 --workload C4 > $O/c4_f17_$1.json 2> $O/c4_f17_$1.err || exit 1
+  timeout -k 10 300 $B --flavour 17 --tf thin > $O/thin_f17_$1.json 2> $O/thin_f17_$1.err || exit 1
+  timeout -k 10 300 $B --flavour 17 --workload C2 > $O/c2_f17_$1.json 2> $O/c2_f17_$1.err || exit 1
+  timeout -k 10 300 $B --flavour 6 > $O/c3_f6_$1.json 2> $O/c3_f6_$1.err || exit 1
+  timeout -k 10 400 $B --flavour 17 --workload C5 --steps 20 > $O/c5_f17_$1.json 2> $O/c5_f17_$1.err || exit 1
+}
+run new
+VR_EXTRA_HIPCC_FLAGS="-DVR_DIST_MAX=16 -DVR_P2_JUMP_MAX=64" python -c "from volumerendering_amd import build as b; b.build_hip()" > $O/build_old.txt 2>&1 || { tail -5 $O/build_old.txt; exit 1; }
+run old
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r4w/*.json')):
+    d=json.load(open(f))
+    row=[f.split('/')[-1]]
+    for k in ('serial','pipelined_one_frame_per_launch','overlapped'):
+        s=d.get(k)
+        if s: row += [k[:6], s['ms_per_step'], s['kernel_ms_median']]
+    print(*row, 'fl', d['config']['kernel_flavour_resolved'], 'scene s', d['config'].get('scene_setup_s'))
+PY
+echo done

@@ -1,0 +1,29 @@
+#!/bin/bash
+# round 4: the approach loop in march_packet too (march_kernel, march_pw_kernel): parity, then A/B on the same box
+O=gpurun_out/r4y
+mkdir -p $O
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1 || { tail -30 $O/tests.txt; exit 1; }
+tail -2 $O/tests.txt
+B="python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-regimes --no-live-pmc --turn-frames 0 --settle 0"
+run() {  # tag
+  timeout -k 10 300 $B --flavour 6 > $O/c3_f6_$1.json 2> $O/c3_f6_$1.err || exit 1
+  timeout -k 10 300 $B --flavour 18 > $O/c3_f18_$1.json 2> $O/c3_f18_$1.err || exit 1
+  timeout -k 10 300 $B --flavour 12 > $O/c3_f12_$1.json 2> $O/c3_f12_$1.err || exit 1
+  timeout -k 10 300 $B --flavour 6 --workload C4 > $O/c4_f6_$1.json 2> $O/c4_f6_$1.err || exit 1
+  timeout -k 10 300 $B --flavour 6 --workload C2 > $O/c2_f6_$1.json 2> $O/c2_f6_$1.err || exit 1
+  timeout -k 10 400 $B --flavour 6 --workload C5 --steps 20 > $O/c5_f6_$1.json 2> $O/c5_f6_$1.err || exit 1
+}
+run new
+VR_EXTRA_HIPCC_FLAGS="-DVR_APPROACH=0" python -c "from volumerendering_amd import build as b; b.build_hip()" > $O/build_old.txt 2>&1 || { tail -5 $O/build_old.txt; exit 1; }
+run old
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r4y/*.json')):
+    d=json.load(open(f))
+    row=[f.split('/')[-1]]
+    for k in ('serial','pipelined_one_frame_per_launch','overlapped'):
+        s=d.get(k)
+        if s: row += [k[:6], s['ms_per_step'], s['kernel_ms_median']]
+    print(*row, 'fl', d['config']['kernel_flavour_resolved'])
+PY
+echo done

@@ -159,6 +159,7 @@ struct vr_ctx {
     unsigned p2_window = 0;   // flavours 16 / 17: records per gather window (VR_EXP_P2_WINDOW: the moving window of volumes >= 4 GiB, forced
                               // onto small volumes by the tests; 0 = what the hardware reaches, just below 4 GiB)
     double active_fraction = 1.0;  // share of bricks that are not inert, of the distance field in use
+    float abox[6] = {-3.0e38f, -3.0e38f, -3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};  // uvw box around the active bricks of that field (MarchParams::abox)
     int pw_policy = 1;        // the default (flavour 0) may pick the persistent kernel (VR_EXP_PW_POLICY=0: never)
     std::string err;
 };
@@ -675,6 +676,26 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 VR_HIP(c, hipStreamSynchronize(s));
                 c->active_fraction = nb > 0 ? (double)cnt / (double)nb : 1.0;
             }
+            {   // the box of the active bricks, in uvw with one brick of margin (MarchParams::abox): brick b of axis a holds the
+                // positions with p * bs - kBrickHalf in [b, b + 1), the first and the last brick those beyond them as well
+                int* d_box = reinterpret_cast<int*>(c->d_counters);  // (6 ints: the counters' 24 bytes)
+                int box[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
+                VR_HIP(c, hipMemcpyAsync(d_box, box, sizeof box, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(active_brick_box_kernel, g, b, 0, s, c->brick_dist, P.bnx, P.bny, P.bnz, d_box);
+                VR_HIP(c, hipGetLastError());
+                VR_HIP(c, hipMemcpyAsync(box, d_box, sizeof box, hipMemcpyDeviceToHost, s));
+                VR_HIP(c, hipStreamSynchronize(s));
+                const double bs[3] = {(double)P.bsx, (double)P.bsy, (double)P.bsz};
+                for (int a = 0; a < 3; ++a) {
+                    if (box[3 + a] < 0) {  // (no active brick: every ray misses)
+                        c->abox[a] = 3.0e38f;
+                        c->abox[3 + a] = -3.0e38f;
+                    } else {
+                        c->abox[a] = (float)(((double)box[a] - 1.0 + (double)kBrickHalf) / bs[a]);
+                        c->abox[3 + a] = (float)(((double)box[3 + a] + 2.0 + (double)kBrickHalf) / bs[a]);
+                    }
+                }
+            }
             VR_HIP(c, hipStreamSynchronize(s));
             c->dist_records = (const void*)P.bricks;
             c->dist_epoch = c->brick_epoch;
@@ -683,6 +704,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
             c->dist_rgb = P.use_rgb;
         }
         P.brick_dist = c->brick_dist;
+        for (int a = 0; a < 6; ++a) P.abox[a] = c->abox[a];
     }
 
     // Default choice, second part -- THE PRIOR: what runs before anything has been measured.  Whole frames of the lit / unlit shader

@@ -23,7 +23,10 @@ constexpr int kBrickShift = VR_BRICK_SHIFT;
 constexpr int kBrickCells = 1 << kBrickShift;
 constexpr float kBrickInv = 1.0f / (float)kBrickCells;    // exact
 constexpr float kBrickHalf = 0.5f / (float)kBrickCells;   // half a cell in brick units (the -0.5 of the cell coordinate)
-constexpr int kDistMax = 16;      // cap of the brick distance field (leaps of up to 15 bricks)
+#ifndef VR_DIST_MAX
+#define VR_DIST_MAX 128
+#endif
+constexpr int kDistMax = VR_DIST_MAX;  // cap of the brick distance field (one dilation pass per value when the field is rebuilt; < 255)
 // Storage bricks of the bricked volume copy (DevVolume::bricked): 2^S voxels per axis, S = 2 (4 x 4 x 4 = 1 KiB of vec4 voxels)
 // by default; -DVR_VOX_BRICK_SHIFT=1 / 3 rebuilds with 2^3- / 8^3-voxel bricks for A/B (tools/run_r3l.sh).
 #ifndef VR_VOX_BRICK_SHIFT
@@ -102,6 +105,7 @@ struct MarchParams {
     const unsigned char* brick_dist;  // per brick: 0 = active; k >= 1 = inert and every brick within Chebyshev
                                       // distance k-1 is inert too (capped); rebuilt when the volume / opacity table change
     int skip_vol;            // which volume carries the density that drives the opacity (0, or 2 for VOLUME_MASK)
+    float abox[6];           // uvw box (lo xyz, hi xyz) around the ACTIVE bricks of brick_dist, one brick of margin: outside it nothing is sampled
     int bnx, bny, bnz;       // bricks per axis
     float bsx, bsy, bsz;     // n / kBrickCells per axis of vol[skip_vol] (exact in f32)
     int tf_zero_prefix;      // largest Z with opacity[0..Z] == 0 exactly (-1: none)

@@ -1396,6 +1396,37 @@ __device__ __forceinline__ int steps_inside(f3 p, f3 step, float bx0, float by0,
     return (in0 && f > 0.0f) ? (int)f : 0;
 }
 
+#ifndef VR_APPROACH
+#define VR_APPROACH 1
+#endif
+constexpr bool kApproach = VR_APPROACH != 0;  // the approach loop in front of the march loops (-DVR_APPROACH=0: A/B builds)
+constexpr int kApproachMax = 1024;            // identity steps one iteration of it may take
+// Steps [k0, k1] outside of which the ray's positions certainly lie outside the box [lo, hi] (uvw; the caller's box carries its own
+// margin of a whole brick, far above what the rounded additions of n_steps steps can drift -- 2^-23 per step -- and what this
+// quotient's evaluation in f32 can be off by: 0.1 % + 2 steps are added on top).  A ray that misses the box: k0 = INT_MAX, k1 = -1.
+// NaN anywhere -> no step is excluded.
+__device__ __forceinline__ void steps_near_box(f3 p, f3 s, const float* box, int n_steps, int& k0, int& k1)
+{
+    const float drift = (float)n_steps * 4.8e-7f;
+    float t0 = 0.0f, t1 = (float)n_steps;
+    bool miss = false;
+    const float pp[3] = {p.x, p.y, p.z}, ss[3] = {s.x, s.y, s.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = box[a] - drift, hi = box[3 + a] + drift;
+        if (ss[a] == 0.0f) {
+            miss = miss || pp[a] < lo || pp[a] > hi;
+        } else {
+            const float ta = (lo - pp[a]) / ss[a], tb = (hi - pp[a]) / ss[a];
+            t0 = fmaxf(t0, fminf(ta, tb));  // (fminf / fmaxf drop a NaN operand)
+            t1 = fminf(t1, fmaxf(ta, tb));
+        }
+    }
+    miss = miss || t0 > t1 + 4.0f;
+    k0 = miss ? 0x7fffffff : max((int)fminf(t0 * 0.999f, 2.0e9f) - 2, 0);
+    k1 = miss ? -1 : (int)fminf(t1 * 1.001f + 3.0f, 2.0e9f);
+}
+
 // OTF (V_LIGHT only): the corners' gradients are derived from the density plane (fetch_rgba_otf) instead of read from
 // the vec4 voxels; the host asks for it when the volume's .rgb is verified to be PreComputeGradient(false) of its .a.
 // The whole march of one ray (ray set-up, per-pixel prologue, the loop): what a lane does for its pixel `slot`.  Shared by
@@ -1463,12 +1494,47 @@ __device__ __forceinline__ void march_packet(const MarchParams& P, const PixelSl
                 Fetch4 F4;
                 Fetch1 F1;
                 float wfx = 0.0f, wfy = 0.0f, wfz = 0.0f;
+                const int lim = min(n_inside, P.steps_count);  // runs stay inside the provably-in-box prefix
+                int i0 = 0;  // the step the loop below starts at
+                if constexpr (kRun && kApproach) {
+                    // THE APPROACH (march_p2_kernel's, vr_p2.h, with votes instead of a wave minimum: the lanes without a ray are
+                    // switched off here): until a ray of the packet stands in an active brick, one byte per ray and the identity
+                    // steps it allows -- the largest power of two every ray allows -- as plain rounded additions; rays outside the
+                    // box of the active bricks (abox) ask for nothing.  The packets that never meet an active brick end here; the
+                    // world position follows only when a ray may still sample.  Every exit is wave-uniform.
+                    const float vmax = fmaxf(fmaxf(fabsf(step.x) * P.bsx, fabsf(step.y) * P.bsy), fabsf(step.z) * P.bsz);
+                    const float lc = 0.999f / vmax;
+                    int k0, k1;
+                    steps_near_box(p, step, P.abox, P.steps_count, k0, k1);
+                    int skipped = 0;
+                    while (vr_ballot(i0 >= lim) == 0) {
+                        const bool near = i0 >= k0 && i0 <= k1;
+                        int safe = kApproachMax;
+                        if (vr_ballot(near) != 0) {
+                            const unsigned d = dist_at(P, brick_of<OFF32>(P, p));
+                            if (vr_ballot(near && d == 0u) != 0) break;
+                            const int sf = 1 + max((int)fminf(((float)d - (1.0f + kBrickHalf)) * lc, (float)kApproachMax), 0);
+                            safe = near ? sf : safe;
+                        }
+                        if (i0 < k0) safe = min(safe, k0 - i0);
+                        safe = min(safe, lim - i0);  // (>= 1)
+                        int sw = 1;
+                        while (sw < kApproachMax && vr_ballot(safe < 2 * sw) == 0) sw *= 2;
+                        for (int k = 0; k < sw; ++k) p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                        i0 += sw;
+                        blends += (unsigned)sw;
+                        skipped += sw;
+                    }
+                    if constexpr (V != V_BASIC && V != V_TF_CALIB) {
+                        if (skipped != 0 && vr_ballot(i0 <= k1) != 0)
+                            for (int k = 0; k < skipped; ++k) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                    }
+                }
                 if constexpr (SKIP) {
                     D = dist_at(P, brick_of<OFF32>(P, p));
                     Dq = dist_at(P, brick_of<OFF32>(P, mk3(p.x + step.x, p.y + step.y, p.z + step.z)));
                     asm volatile("" : "+v"(D));  // wait for D here; Dq stays in flight
                 }
-                const int lim = min(n_inside, P.steps_count);  // runs stay inside the provably-in-box prefix
                 const int prio_q1 = P.steps_count >> 2, prio_q2 = P.steps_count >> 1, prio_q3 = prio_q1 + prio_q2;
                 // kRun: steps a ray at distance-field value D can take while it certainly stays within D-1 bricks of
                 // its brick on every axis = (D - 1 - 1/16) / (largest per-step move in brick units), 0.1 % short
@@ -1477,7 +1543,7 @@ __device__ __forceinline__ void march_packet(const MarchParams& P, const PixelSl
                     const float vmax = fmaxf(fmaxf(fabsf(step.x) * P.bsx, fabsf(step.y) * P.bsy), fabsf(step.z) * P.bsz);
                     leap_c = 0.999f / vmax;  // vmax 0 -> inf (capped below), NaN -> n_inside is 0 and nothing leaps
                 }
-                for (int i = 0; i < P.steps_count;) {
+                for (int i = i0; i < P.steps_count;) {
                     f3 pn = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
                     const f3 pq = mk3(pn.x + step.x, pn.y + step.y, pn.z + step.z);
                     if constexpr (SKIP) {
@@ -1983,6 +2049,33 @@ __global__ void count_active_bricks_kernel(const unsigned char* __restrict__ dis
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long m = vr_ballot(i < n && dist[i] == 0);
     if ((threadIdx.x & 63) == 0 && m != 0) atomicAdd(out, (unsigned)__popcll(m));
+}
+
+// the box of the active bricks (brick coordinates, inclusive; out[0..2] start at INT_MAX, out[3..5] at -1): a ray whose positions stay
+// outside it -- one brick of margin -- samples nothing, whatever the distance field says about the bricks on its way (march_p2_kernel's
+// approach loop)
+__global__ void active_brick_box_kernel(const unsigned char* __restrict__ dist, int bnx, int bny, int bnz, int* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+    if (i < bnx * bny * bnz && dist[i] == 0) {
+        lo[0] = hi[0] = i % bnx;
+        lo[1] = hi[1] = (i / bnx) % bny;
+        lo[2] = hi[2] = i / (bnx * bny);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = min(lo[a], __shfl_down(lo[a], off, 64));
+            hi[a] = max(hi[a], __shfl_down(hi[a], off, 64));
+        }
+    if ((threadIdx.x & 63) == 0 && hi[0] >= 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(out + a, lo[a]);
+            atomicMax(out + 3 + a, hi[a]);
+        }
+    }
 }
 
 // VOLUME_MASK looks at two volumes on one grid: record = (max density of the CT, max(r,g,b) of the mask)

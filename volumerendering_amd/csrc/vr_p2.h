@@ -23,6 +23,15 @@
 namespace VR_KNS {
 using namespace vr;
 
+#ifndef VR_P2_JUMP_MAX
+#define VR_P2_JUMP_MAX 1024
+#endif
+constexpr int kP2JumpMax = VR_P2_JUMP_MAX;  // identity steps one trip may skip (each three rounded additions per ray, six with a world position)
+#ifndef VR_P2_EXIT
+#define VR_P2_EXIT 1
+#endif
+constexpr bool kP2Exit = kApproach && VR_P2_EXIT != 0;  // ... and the same knowledge behind the box of the active bricks (A/B: -DVR_P2_EXIT=0)
+constexpr bool kP2Approach = kApproach;  // the approach loop in front of the pipelined loop (-DVR_APPROACH=0: A/B builds)
 constexpr int kP2Threads = 768;  // at most 12 wavefronts per CU, 3 per SIMD (two corner buffers are 64 of ~168 VGPRs)
 
 // (indexed buffer loads -- vr_struct_load_b128 / _b32 -- are declared in vr_kernels.h)
@@ -230,6 +239,9 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
     static_assert(V == V_LIGHT || V == V_BASIC || (V == V_VOLUME_MASK && SKIP), "lit / unlit shader; the three-volume composite with its brick records");
     constexpr int kSrc = (V == V_VOLUME_MASK) ? 2 : 0;  // the volume that is pipelined: the CT of the composite (VolumeMaskApp.wgsl:187)
     constexpr bool kLit = V != V_BASIC;                 // 16-byte voxels (gradient + density) / 4-byte densities
+    // (the one-frame >= 4 GiB kernel is at the register limit: one more value across its loop costs a scratch reload in it -- C5 3.48 ->
+    // 3.59 ms; its several-frames form and every other form gain: tools/experiments/r4z.sh)
+    constexpr bool kExit = SKIP && kP2Exit && !(WIN && !BATCH);
     const MarchParams& P0 = B.frame[0];                 // what every frame of the launch shares: volumes, tables, brick records
     const DevVolume& vol = P0.vol[kSrc];
     P2Lds L;
@@ -520,12 +532,52 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 alive = alive && can_blend<V>(dst.w);
                 if constexpr (kLit) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
             };
+            int k_last = 0x7fffffff;  // no step of the ray behind this one can lie in an active brick (steps_near_box)
+            if constexpr (SKIP && kP2Approach) {
+                // THE APPROACH: until a ray of the packet stands in an active brick nothing is requested ahead -- a byte per ray, the
+                // identity steps it allows (march_packet's run length, and one for the position itself), the wave's minimum of them
+                // as plain rounded additions.  A packet that never meets an active brick (C3: 7 775 of the 12 214 packets whose rays
+                // cross the box, 22 % of the frame's wavefront time when they went through the pipelined loop's trips) ends here.
+                // Rays outside the box of the active bricks (abox; steps_near_box) ask for nothing at all: before it they are safe up
+                // to it, behind it to the end.  The world position follows when a ray may still sample (it is only read by the shading).
+                int k0, k1;
+                steps_near_box(pA, step, P0.abox, steps_count, k0, k1);
+                if constexpr (kExit) k_last = k1;
+                int skipped = 0;  // (wave-uniform) steps taken here
+                while (i < n_in_w && vr_ballot(alive) != 0) {
+                    const bool near = alive && i >= k0 && i <= k1;
+                    int safe = kP2JumpMax;  // identity steps from step i on
+                    if (vr_ballot(near) != 0) {
+                        const unsigned d = dist_at(P0, brick_of<true>(P0, pA));
+                        if (vr_ballot(near && d == 0u) != 0) break;
+                        const int sf = 1 + max((int)fminf(((float)d - (1.0f + kBrickHalf)) * leap_c, (float)kP2JumpMax), 0);
+                        safe = near ? sf : safe;
+                    }
+                    if (alive && i < k0) safe = min(safe, k0 - i);
+                    safe = alive ? min(safe, lim - i) : kP2JumpMax;
+                    const int sw = wave_min_i32(safe);  // (>= 1: every marching ray has lim > i, an inert brick, or steps to go to its k0)
+                    for (int k = 0; k < sw; ++k) pA = mk3(pA.x + step.x, pA.y + step.y, pA.z + step.z);
+                    if (alive) blends += (unsigned)sw;
+                    i += sw;
+                    skipped += sw;
+                }
+                if constexpr (kLit) {
+                    if (skipped != 0 && vr_ballot(alive && i <= k1) != 0)
+                        for (int k = 0; k < skipped; ++k) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
+                }
+                p = pA;
+                pB = pA;
+            }
             bool start = true;  // (wave-uniform) nothing is in flight yet
 #if VR_P2_DEBUG
             dbg_trips = dbg_sampled = dbg_shaded = dbg_jumps = 0;
             dbg_loop = __builtin_readcyclecounter();
 #endif
             while (i + 2 <= n_in_w && vr_ballot(alive) != 0) {
+                if constexpr (kExit) {
+                    // (no marching ray can meet an active brick any more: what is left are identity steps -- below)
+                    if (vr_ballot(alive && i <= k_last) == 0) break;
+                }
                 if (start) {
                     // the bytes of pA and pB and, without waiting for them, the corners of steps 0 and 1 of every ray
                     pB = mk3(pA.x + step.x, pA.y + step.y, pA.z + step.z);
@@ -559,12 +611,12 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                     idle_a = da >= 1u;
                     idle_b = db >= 1u;
                     // steps after pB the ray certainly spends in inert bricks (march_packet's run length; < 0 at an active brick)
-                    int m = min((int)fminf(((float)db - (1.0f + kBrickHalf)) * leap_c, 64.0f), lim - (i + 1) - 1);
-                    m = alive ? m : 64;
+                    int m = min((int)fminf(((float)db - (1.0f + kBrickHalf)) * leap_c, (float)kP2JumpMax), lim - (i + 1) - 1);
+                    m = alive ? m : kP2JumpMax;
                     // (Round 3 jumped by 4, 8 .. 64 steps, decided by up to five votes: a gap of one to three steps -- the packet's rays
                     // reach an active brick a few steps apart -- was walked as idle steps, each the price of a request.  A jump costs
                     // three additions per step: every marching ray's safe steps, however few, are jumped, by exactly their minimum.)
-                    if (vr_ballot(m < 1) == 0) mw = min(wave_min_i32(m), 64);
+                    if (vr_ballot(m < 1) == 0) mw = min(wave_min_i32(m), kP2JumpMax);
                     idle_ra = m >= mw + 1;  // the positions requested now are steps mw + 1 and mw + 2 after pB
                     idle_rb = m >= mw + 2;
                 }
@@ -599,13 +651,23 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
             // loop costs about what a pipelined step costs (13 % of the cycles for about as many of the steps): keeping the
             // pipelined loop going with ever fewer rays saves nothing, and the parked rays' steps here come on top.)
             if (!start) p = pA;
+            if constexpr (kExit) {
+                // behind the box of the active bricks: the steps up to the packet's provably-in-box prefix are plain rounded additions
+                // (the world position is not read again), and the loop below asks for no byte
+                if (i < n_in_w && vr_ballot(alive) != 0 && vr_ballot(alive && i <= k_last) == 0) {
+                    const int sw = n_in_w - i;
+                    for (int k = 0; k < sw; ++k) p = mk3(p.x + step.x, p.y + step.y, p.z + step.z);
+                    if (alive) blends += (unsigned)sw;
+                    i += sw;
+                }
+            }
             for (; i < steps_count && vr_ballot(alive) != 0; ++i) {
                 if (alive) {
                     bool inb = true;
                     if (i >= n_inside) inb = p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1;
                     if (inb) {
                         bool sampled = true;
-                        if constexpr (SKIP) sampled = dist_at(P0, brick_of<true>(P0, p)) == 0u;
+                        if constexpr (SKIP) sampled = i <= k_last && dist_at(P0, brick_of<true>(P0, p)) == 0u;
                         if (sampled) {
                             sample_and_blend<V, !WIN, false, SKIP, true>(P, p, w, dst, mk3(0.0f, 0.0f, 0.0f), 0.0f);
                             ++fetched;
