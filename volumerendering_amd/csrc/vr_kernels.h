@@ -1417,7 +1417,8 @@ __device__ __forceinline__ void steps_near_box(f3 p, f3 s, const float* box, int
         if (ss[a] == 0.0f) {
             miss = miss || pp[a] < lo || pp[a] > hi;
         } else {
-            const float ta = (lo - pp[a]) / ss[a], tb = (hi - pp[a]) / ss[a];
+            const float inv = __builtin_amdgcn_rcpf(ss[a]);  // (1 ulp: the margins below are a thousand times that)
+            const float ta = (lo - pp[a]) * inv, tb = (hi - pp[a]) * inv;
             t0 = fmaxf(t0, fminf(ta, tb));  // (fminf / fmaxf drop a NaN operand)
             t1 = fminf(t1, fmaxf(ta, tb));
         }

@@ -3,6 +3,17 @@
 // multiply-adds) and by vr_fused.hip (namespace vrf, fused multiply-adds); enqueue_render calls the one the context's
 // arithmetic mode selects (vr_set_arithmetic).
 #pragma once
+// march_p2_kernel: the several-frames form also for a launch of ONE frame.  It reads a frame's parameters where it uses them, through
+// a wave-uniform index, and keeps fewer of them in registers: no scratch reload in the pipelined loop, which the one-frame form of the
+// >= 4 GiB kernel has at the register limit (C5 3.37 -> 2.94 ms, a rank's half of it 1.78 -> 1.57), and 1 % on C3 / C4 below 4 GiB
+// (tools/experiments/r5a.sh, r5b.sh).  -DVR_P2_WIN_BATCH=0 / -DVR_P2_ALL_BATCH=0 build and launch the one-frame forms (A/B).
+#ifndef VR_P2_ALL_BATCH
+#define VR_P2_ALL_BATCH 1
+#endif
+#ifndef VR_P2_WIN_BATCH
+#define VR_P2_WIN_BATCH 1
+#endif
+
 #include "../../include/vr.h"
 #include "vr_kernels.h"
 #include "vr_dp.h"
@@ -138,15 +149,19 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         }                                                                                                              \
         hipLaunchKernelGGL(k, L.grid, L.block, L.lds_bytes, s, B, L.queue);                                            \
     } while (0)
+#define VR_LAUNCH_P2_F(S, WN, ALWAYS)                                                                                   \
+    do {                                                                                                               \
+        if constexpr ((ALWAYS) != 0) {                                                                                 \
+            VR_LAUNCH_P2(S, WN, true);                                                                                 \
+        } else {                                                                                                       \
+            if (B.n_frames > 1) VR_LAUNCH_P2(S, WN, true);                                                             \
+            else VR_LAUNCH_P2(S, WN, false);                                                                           \
+        }                                                                                                              \
+    } while (0)
 #define VR_LAUNCH_P2_W(S)                                                                                              \
     do {                                                                                                               \
-        if (L.pw_p2_win) {                                                                                             \
-            if (B.n_frames > 1) VR_LAUNCH_P2(S, true, true);                                                           \
-            else VR_LAUNCH_P2(S, true, false);                                                                         \
-        } else {                                                                                                       \
-            if (B.n_frames > 1) VR_LAUNCH_P2(S, false, true);                                                          \
-            else VR_LAUNCH_P2(S, false, false);                                                                        \
-        }                                                                                                              \
+        if (L.pw_p2_win) VR_LAUNCH_P2_F(S, true, VR_P2_WIN_BATCH);                                                     \
+        else VR_LAUNCH_P2_F(S, false, VR_P2_ALL_BATCH);                                                                \
     } while (0)
             if constexpr (V == V_VOLUME_MASK) {
                 VR_LAUNCH_P2_W(true);  // (the host asks for it only with the brick records in place)
@@ -155,6 +170,7 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
                 else VR_LAUNCH_P2_W(false);
             }
 #undef VR_LAUNCH_P2_W
+#undef VR_LAUNCH_P2_F
 #undef VR_LAUNCH_P2
             return;
         }

@@ -16,6 +16,12 @@
 //     (frame, packet) items, the frames interleaved so that the long packets of every frame start first;
 //   * V_VOLUME_MASK (BASELINE config 4): the CT volume is pipelined, mask and dose are fetched on demand behind the per-brick
 //     mask record, which rides along with the distance-field byte.
+//   * THE APPROACH: in front of the pipelined loop a packet walks its identity steps without asking for anything ahead -- one
+//     distance-field byte per ray and the wave's minimum of the steps they allow, as plain rounded additions -- until a ray stands in
+//     an active brick; rays outside the uvw box of the active bricks (MarchParams::abox, steps_near_box) ask for nothing at all, and
+//     behind that box the pipelined loop is left.  The packets that cross the volume without ever meeting an active brick (C3: 64 %
+//     of the packets that cross it, 22 % of the frame's wavefront time when their jumps were trips of the pipelined loop) end
+//     there: C3 one frame at a time 0.522 -> 0.477 ms.
 // Arithmetic, positions, blend order and counts are march_packet's (vr_kernels.h): bit-identical frames and records.
 #pragma once
 #include "vr_pw.h"
@@ -239,9 +245,11 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
     static_assert(V == V_LIGHT || V == V_BASIC || (V == V_VOLUME_MASK && SKIP), "lit / unlit shader; the three-volume composite with its brick records");
     constexpr int kSrc = (V == V_VOLUME_MASK) ? 2 : 0;  // the volume that is pipelined: the CT of the composite (VolumeMaskApp.wgsl:187)
     constexpr bool kLit = V != V_BASIC;                 // 16-byte voxels (gradient + density) / 4-byte densities
-    // (the one-frame >= 4 GiB kernel is at the register limit: one more value across its loop costs a scratch reload in it -- C5 3.48 ->
-    // 3.59 ms; its several-frames form and every other form gain: tools/experiments/r4z.sh)
-    constexpr bool kExit = SKIP && kP2Exit && !(WIN && !BATCH);
+    // (the one-frame >= 4 GiB kernel is at the register limit: with the approach loop in front its pipelined loop reloads two register
+    // pairs from scratch per step -- C5 3.39 -> 3.45 ms, with the exit test 3.59, a rank's half of C5 1.82 -> 2.00; its several-frames
+    // form and every other form gain: tools/experiments/r4x.sh, r4z.sh)
+    constexpr bool kApproachHere = SKIP && kP2Approach && !(WIN && !BATCH);
+    constexpr bool kExit = kApproachHere && kP2Exit;
     const MarchParams& P0 = B.frame[0];                 // what every frame of the launch shares: volumes, tables, brick records
     const DevVolume& vol = P0.vol[kSrc];
     P2Lds L;
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
                 if constexpr (kLit) w = mk3(w.x + wstep.x, w.y + wstep.y, w.z + wstep.z);
             };
             int k_last = 0x7fffffff;  // no step of the ray behind this one can lie in an active brick (steps_near_box)
-            if constexpr (SKIP && kP2Approach) {
+            if constexpr (kApproachHere) {
                 // THE APPROACH: until a ray of the packet stands in an active brick nothing is requested ahead -- a byte per ray, the
                 // identity steps it allows (march_packet's run length, and one for the position itself), the wave's minimum of them
                 // as plain rounded additions.  A packet that never meets an active brick (C3: 7 775 of the 12 214 packets whose rays
