@@ -6,7 +6,8 @@
 // march_p2_kernel: the several-frames form also for a launch of ONE frame.  It reads a frame's parameters where it uses them, through
 // a wave-uniform index, and keeps fewer of them in registers: no scratch reload in the pipelined loop, which the one-frame form of the
 // >= 4 GiB kernel has at the register limit (C5 3.37 -> 2.94 ms, a rank's half of it 1.78 -> 1.57), and 1 % on C3 / C4 below 4 GiB
-// (tools/experiments/r5a.sh, r5b.sh).  -DVR_P2_WIN_BATCH=0 / -DVR_P2_ALL_BATCH=0 build and launch the one-frame forms (A/B).
+// (tools/experiments/r5a.sh, r5b.sh).  The template argument BATCH still names the launch -- one frame or several: two kernel names in
+// a profile -- the code behind both is the same (vr_p2.h: kMulti).  -DVR_P2_WIN_BATCH=0 / -DVR_P2_ALL_BATCH=0: the one-frame code (A/B).
 #ifndef VR_P2_ALL_BATCH
 #define VR_P2_ALL_BATCH 1
 #endif
@@ -149,19 +150,15 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         }                                                                                                              \
         hipLaunchKernelGGL(k, L.grid, L.block, L.lds_bytes, s, B, L.queue);                                            \
     } while (0)
-#define VR_LAUNCH_P2_F(S, WN, ALWAYS)                                                                                   \
-    do {                                                                                                               \
-        if constexpr ((ALWAYS) != 0) {                                                                                 \
-            VR_LAUNCH_P2(S, WN, true);                                                                                 \
-        } else {                                                                                                       \
-            if (B.n_frames > 1) VR_LAUNCH_P2(S, WN, true);                                                             \
-            else VR_LAUNCH_P2(S, WN, false);                                                                           \
-        }                                                                                                              \
-    } while (0)
 #define VR_LAUNCH_P2_W(S)                                                                                              \
     do {                                                                                                               \
-        if (L.pw_p2_win) VR_LAUNCH_P2_F(S, true, VR_P2_WIN_BATCH);                                                     \
-        else VR_LAUNCH_P2_F(S, false, VR_P2_ALL_BATCH);                                                                \
+        if (L.pw_p2_win) {                                                                                             \
+            if (B.n_frames > 1) VR_LAUNCH_P2(S, true, true);                                                           \
+            else VR_LAUNCH_P2(S, true, false);                                                                         \
+        } else {                                                                                                       \
+            if (B.n_frames > 1) VR_LAUNCH_P2(S, false, true);                                                          \
+            else VR_LAUNCH_P2(S, false, false);                                                                        \
+        }                                                                                                              \
     } while (0)
             if constexpr (V == V_VOLUME_MASK) {
                 VR_LAUNCH_P2_W(true);  // (the host asks for it only with the brick records in place)
@@ -170,7 +167,6 @@ void launch_pw(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
                 else VR_LAUNCH_P2_W(false);
             }
 #undef VR_LAUNCH_P2_W
-#undef VR_LAUNCH_P2_F
 #undef VR_LAUNCH_P2
             return;
         }

@@ -248,7 +248,11 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
     // (the one-frame >= 4 GiB kernel is at the register limit: with the approach loop in front its pipelined loop reloads two register
     // pairs from scratch per step -- C5 3.39 -> 3.45 ms, with the exit test 3.59, a rank's half of C5 1.82 -> 2.00; its several-frames
     // form and every other form gain: tools/experiments/r4x.sh, r4z.sh)
-    constexpr bool kApproachHere = SKIP && kP2Approach && !(WIN && !BATCH);
+    // BATCH names the launch (several frames / one); kMulti is the code: the several-frames form -- a frame's parameters read where they
+    // are used, through a wave-uniform index -- also for one frame per launch (vr_launch.h: VR_P2_ALL_BATCH / VR_P2_WIN_BATCH; the
+    // one-frame launches keep a kernel name of their own in the profiles)
+    constexpr bool kMulti = BATCH || (WIN ? VR_P2_WIN_BATCH != 0 : VR_P2_ALL_BATCH != 0);
+    constexpr bool kApproachHere = SKIP && kP2Approach && !(WIN && !kMulti);
     constexpr bool kExit = kApproachHere && kP2Exit;
     const MarchParams& P0 = B.frame[0];                 // what every frame of the launch shares: volumes, tables, brick records
     const DevVolume& vol = P0.vol[kSrc];
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
     const unsigned groups = (gridDim.x - cls + 7u) >> 3;
     const unsigned wib = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned wpb = blockDim.x >> 6;
-    const unsigned nf = BATCH ? B.n_frames : 1u;
+    const unsigned nf = kMulti ? B.n_frames : 1u;
     const unsigned n_c = (Q.n_items >> 3) * nf;  // items per class: every frame's packets of the class, the frames interleaved
     // first item: static (wavefront k of every workgroup before wavefront k + 1 of any: the longest packets are dealt over the CUs, no
     // atomic at the start of the launch) -- or, Q.dynamic (launches in flight: workgroups start when others retire, and the
@@ -308,13 +312,13 @@ __global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B
         if (idx >= n_c) break;  // (the class's queue has run dry: the wavefront leaves)
         // item idx of the class = packet idx / nf (in the launch order) of frame idx % nf
         unsigned item = idx, frame = 0;
-        if constexpr (BATCH) {
+        if constexpr (kMulti) {
             item = batch_group(idx, nf);
             frame = idx - item * nf;
         }
         // (the frame's parameters through a wave-uniform index, said so explicitly: scalar loads; behind an index the compiler takes
         // for divergent they become vector loads -- in the middle of the pipelined loop, whose wait counts they then drain)
-        const MarchParams& P = B.frame[BATCH ? (unsigned)__builtin_amdgcn_readfirstlane((int)frame) : 0u];
+        const MarchParams& P = B.frame[kMulti ? (unsigned)__builtin_amdgcn_readfirstlane((int)frame) : 0u];
         // what the step loop reads of the frame, once per packet
         const f3 light_pos = mk3(P.light_pos[0], P.light_pos[1], P.light_pos[2]), light_dif = mk3(P.light_dif[0], P.light_dif[1], P.light_dif[2]),
                  light_amb = mk3(P.light_amb[0], P.light_amb[1], P.light_amb[2]);
