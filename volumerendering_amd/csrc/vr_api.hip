@@ -711,13 +711,14 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
     // and of the composite, one launch at a time: the kernel with the corner loads two steps ahead (vr_p2.h) -- 17, or 16 where next to
     // nothing can be skipped (noisy air under the default ramp 2.95 -> 1.97 ms; C3 0.65 -> 0.51; C4 0.72 -> 0.57) -- unless an earlier
     // launch of this shape says its chains are short (C2, longest chain 102: a packet is too short for the pipeline's fill and a
-    // dequeue, 0.111 -> 0.161).  With launches in flight, several frames per launch and shares of a frame: the first part's choice.
+    // dequeue, 0.111 -> 0.161).  The same with launches in flight and several frames per launch since the approach loop (C3 0.417 / 0.382
+    // ms per frame against march_kernel's 0.464 / 0.445; C5 level); shares of a frame: the first part's choice.
     const bool p2_variant = variant == VR_VARIANT_LIGHT || variant == VR_VARIANT_BASIC || (variant == VR_VARIANT_VOLUME_MASK && can_skip);
     const long long px_all = (long long)tile_count(c, rank, world) * kTile * kTile;
     const bool whole_frame = (double)px_all / ((double)c->n_cus * 4.0 * 5.0 * 64.0) >= 4.5;
     const bool nothing_to_skip = !can_skip || c->active_fraction >= 0.9;
     const bool auto_choice = c->flavour == 0 && c->default_flavour == 0;
-    if (auto_choice && c->pw_policy && fl == 6 && n_frames == 1 && c->frames_in_flight == 1 && whole_frame && p2_ok && p2_variant) {
+    if (auto_choice && c->pw_policy && fl == 6 && whole_frame && p2_ok && p2_variant) {
         const bool short_chains = chain_known != 0 && chain_known - 1 < 128;
         if (nothing_to_skip && variant != VR_VARIANT_VOLUME_MASK) fl = 16;
         else if (!short_chains) fl = 17;

@@ -21,7 +21,7 @@
 //     an active brick; rays outside the uvw box of the active bricks (MarchParams::abox, steps_near_box) ask for nothing at all, and
 //     behind that box the pipelined loop is left.  The packets that cross the volume without ever meeting an active brick (C3: 64 %
 //     of the packets that cross it, 22 % of the frame's wavefront time when their jumps were trips of the pipelined loop) end
-//     there: C3 one frame at a time 0.522 -> 0.477 ms.
+//     there: C3 one frame at a time 0.522 -> 0.476 ms.
 // Arithmetic, positions, blend order and counts are march_packet's (vr_kernels.h): bit-identical frames and records.
 #pragma once
 #include "vr_pw.h"
