@@ -414,12 +414,13 @@ def test_measured_kernel_choice_with_interleaved_shapes():
 
 def blob_volume(n, lo, hi, lit):
     """Density 0 everywhere but a box of voxels [lo, hi) per axis (0.2 .. 0.9, varying), with its gradient for the lit shader:
-    the active bricks' box is small, off-centre, and may touch the volume's edge."""
-    a = np.zeros((n, n, n), dtype=f32)
-    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    the active bricks' box is small, off-centre, and may touch the volume's edge.  n: voxels per axis, or (nx, ny, nz)."""
+    nx, ny, nz = (n, n, n) if np.isscalar(n) else n
+    a = np.zeros((nz, ny, nx), dtype=f32)
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
     inside = ((x >= lo[0]) & (x < hi[0]) & (y >= lo[1]) & (y < hi[1]) & (z >= lo[2]) & (z < hi[2]))
     a[inside] = (0.2 + 0.7 * ((x + 2 * y + 3 * z) % 17) / 16.0).astype(f32)[inside]
-    v = np.zeros((n, n, n, 4), dtype=f32)
+    v = np.zeros((nz, ny, nx, 4), dtype=f32)
     v[..., 3] = a
     if lit:
         v = ob.precompute_gradient(np.ascontiguousarray(v), False)  # (the oracle's PreComputeGradient: VolumeFile.cpp:196-257)
@@ -460,3 +461,25 @@ def test_box_of_the_active_bricks(blob, variant):
             for fl in (17, 12):
                 assert np.array_equal(recs[6][:, :3], recs[fl][:, :3]), (kw, fl)
             assert np.array_equal(recs[6][:, :2], recs[1][:, :2]), kw  # (1 fetches every in-box sample: its third word differs)
+
+
+def test_box_of_the_active_bricks_in_a_volume_with_three_different_sides():
+    """The same with nx != ny != nz (the box is kept in uvw: one scale per axis, bricks that hang over the volume's far faces) and
+    a blob that is not aligned with the bricks."""
+    dims, W, H = (40, 22, 57), 160, 96
+    step, count = hr.stepping_params(*dims)
+    tfs = [zero_prefix_tf(64, 3, top=0.5)]
+    for lo, hi in (((21, 3, 30), (38, 9, 49)), ((0, 17, 50), (5, 22, 57))):
+        vols = [blob_volume(dims, lo, hi, True)]
+        with capi.Context(W, H, 0) as ctx:
+            for kw in CAMERAS[:7] + [dict(yaw=0.3, pitch=0.2, distance=0.15)]:
+                args = dict(steps_count=count, step_size=step)
+                args.update(kw)
+                u = hr.make_uniforms(W, H, **args)
+                recs = {}
+                for fl in (6, 17):
+                    ctx.set_kernel_flavour(fl)
+                    check(ctx, capi.LIGHT, u, vols, tfs, W, H)
+                    assert ctx.last_kernel_flavour() == fl
+                    recs[fl] = ctx.block_trace().astype(np.uint64)
+                assert np.array_equal(recs[6][:, :3], recs[17][:, :3]), kw

@@ -149,6 +149,9 @@ __device__ __forceinline__ void march_dp_body(const MarchParams& P, const PixelS
     // ---- the march: every lane of the wavefront runs the loop (rays that are done are predicated off), so the
     // quad broadcasts and the wavefront votes below always see all their lanes
     constexpr bool kW = (V != V_BASIC && V != V_TF_CALIB);  // the shader uses the world position
+    // (The approach loop of march_p2_kernel / march_packet -- no look-ups outside the box of the active bricks, identity steps as plain
+    // additions until a ray stands in an active brick -- was built here too, bit-exact, and is no gain for these kernels: a rank's quarter
+    // of C3 with four lanes per ray 0.251 -> 0.285 ms, its eighth 0.193 -> 0.201, with two lanes level (tools/experiments/r5c.sh).)
     // depth slot j starts j steps down the ray: the same rounded additions the one-lane loop performs
 #pragma unroll
     for (int k = 0; k < K - 1; ++k) {
