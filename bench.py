@@ -73,7 +73,7 @@ KERNEL_OF_FLAVOUR = {1: "march_kernel (no skipping)", 2: "march_wtb_light_kernel
                      13: "march_pw_kernel (persistent wavefronts, TF slot 0 in LDS, corner loads pipelined)",
                      18: "march_kernel (one lane per ray, slot arithmetic from LDS tables)",
                      16: "march_p2_kernel (persistent wavefronts, indexed corner loads two steps ahead, slot tables in LDS, no skipping)",
-                     17: "march_p2_kernel (persistent wavefronts, indexed corner loads two steps ahead, slot tables in LDS, skipping decided ahead of the loads)"}
+                     17: "march_p2_kernel (persistent wavefronts, approach loop, indexed corner loads two steps ahead, slot tables in LDS, skipping decided ahead of the loads)"}
 
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"],
