@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the hand-back and its knobs VR_P2_BACK / VR_EXP_P2_BACK were removed after this measurement: DESIGN 7)
 # round 4: the pipelined loop hands a run of >= VR_P2_BACK identity steps back to the approach loop: A/B against -DVR_P2_BACK=0
 O=gpurun_out/r5d
 mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the hand-back and its knobs VR_P2_BACK / VR_EXP_P2_BACK were removed after this measurement: DESIGN 7)
 # round 4: the hand-back threshold of the >= 4 GiB kernels (VR_P2_BACK): 8 against 32 on C5 and a rank's half / eighth of it
 O=gpurun_out/r5e2
 mkdir -p $O

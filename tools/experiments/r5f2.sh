@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the hand-back and its knobs VR_P2_BACK / VR_EXP_P2_BACK were removed after this measurement: DESIGN 7)
 # round 4: C5, the hand-back to the approach loop on / off, alternating twice on one box (VR_EXP_P2_BACK)
 O=gpurun_out/r5f2
 mkdir -p $O
