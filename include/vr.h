@@ -309,7 +309,7 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
 /* Kernel flavour for A/B measurements.  All flavours are bit-identical in output and in the composited / covered counts; the
  * FETCHED count (vr_last_counters out[2]) is the same for all but 1 and 16, which skip nothing and fetch every composited sample
  * -- the default may pick 16 for volumes with next to nothing to skip, so `fetched` can differ between frames of one scene.
- * (2, 3, 4, 5 and 9 exist only in builds with -DVR_EXPERIMENTAL_FLAVOURS=1: vr_experimental_flavours below.)
+ * (2, 3, 4, 5, 9 and 14 exist only in builds with -DVR_EXPERIMENTAL_FLAVOURS=1: vr_experimental_flavours below.)
  *   0  default: a MEASURED choice.  Every form below gives the same bits, so the context tries the eligible ones on the
  *      caller's own frames -- three launches each (frames in flight + 3 with launches in flight), behind a few launches of the
  *      prior's pick so that a launch order exists -- and keeps the fastest by the launches' own records (no synchronisation: the
@@ -347,7 +347,8 @@ int vr_last_block_trace(vr_ctx* ctx, uint64_t* out, int capacity);
  *   14  (experimental build) lanes per ray chosen PER PACKET (csrc/vr_mixed.h): packets whose longest ray chain in an earlier
  *      launch of the same shape reached 75 % of that launch's longest are marched as two half packets with two lanes per ray,
  *      the rest with one; one-frame launches of the shaders that have a depth-parallel form
- *   15  (experimental build) LDS tiles filled by LDS-DMA (csrc/vr_lt.h): lit shader, launches of one frame          */
+ *   15  the voxels of a packet's next four steps in an LDS tile filled by LDS-DMA (csrc/vr_lt.h): lit shader, launches of
+ *       one frame (other launches run 6); never picked by the default -- slower than 17 / 16 wherever measured            */
 int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 
 /* What the default's measured choice (flavour 0) knows about the launch shape it was asked for last: the candidates' flavours, the
@@ -357,7 +358,7 @@ int vr_set_kernel_flavour(vr_ctx* ctx, int flavour);
 int vr_kernel_choice(vr_ctx* ctx, int flavours[6], float ms_per_launch[6], int* chosen);
 
 /* 1 if the library was built with -DVR_EXPERIMENTAL_FLAVOURS=1: the kernel forms that lost every A/B -- flavours 2, 3, 4, 5, 9,
- * 14, 15 and volume layout 2 -- are then compiled in; 0 (the shipped build): vr_set_kernel_flavour / vr_set_volume_layout return
+ * 14 and volume layout 2 -- are then compiled in; 0 (the shipped build): vr_set_kernel_flavour / vr_set_volume_layout return
  * VR_ERR_UNSUPPORTED for them.                                                                                           */
 int vr_experimental_flavours(void);
 

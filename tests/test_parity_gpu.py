@@ -1123,7 +1123,6 @@ def test_mixed_lanes_per_ray_at_1080p_and_every_threshold(ctx, monkeypatch):
 
 
 # ---- LDS tiles filled by LDS-DMA (flavour 15, csrc/vr_lt.h) ------------------------------------------------------------------
-@pytest.mark.skipif(not vt.experimental(), reason="flavour 15 needs VR_EXPERIMENTAL_FLAVOURS=1")
 def test_lds_tiles_by_lds_dma(ctx):
     """Flavour 15: the voxels of the next four steps of a packet are fetched once into the wavefront's LDS tile by
     global_load_lds_dwordx4 and the corner gathers read LDS.  Volumes whose boxes fit and volumes whose boxes do not (a 200^3

@@ -85,7 +85,7 @@ def experimental() -> bool:
 
 def flavours(*fl):
     ex = experimental()
-    return [f for f in fl if ex or f not in (2, 3, 4, 5, 9, 14, 15)]
+    return [f for f in fl if ex or f not in (2, 3, 4, 5, 9, 14)]  # (15, the LDS tiles, is part of the shipped library)
 
 
 def layouts(*modes):

@@ -1271,7 +1271,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_PRIO")) c->prio_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_FLAVOUR")) {
         const int f = atoi(e);
-        if (f >= 0 && f <= 18 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9 || f == 14 || f == 15))) c->default_flavour = f;
+        if (f >= 0 && f <= 18 && (VR_EXPERIMENTAL_FLAVOURS || !(f == 2 || f == 3 || f == 4 || f == 5 || f == 9 || f == 14))) c->default_flavour = f;
     }
     if (const char* e = getenv("VR_EXP_XCD")) c->xcd_mode = atoi(e);
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
@@ -1965,8 +1965,8 @@ int vr_set_kernel_flavour(vr_ctx* c, int flavour)
 {
     if (!c) return VR_ERR_INVALID_ARG;
     if (flavour < 0 || flavour > 18) return fail(c, VR_ERR_INVALID_ARG, "vr_set_kernel_flavour: unknown flavour");
-    if (!VR_EXPERIMENTAL_FLAVOURS && (flavour == 2 || flavour == 3 || flavour == 4 || flavour == 5 || flavour == 9 || flavour == 14 || flavour == 15))
-        return fail(c, VR_ERR_UNSUPPORTED, "vr_set_kernel_flavour: flavours 2, 3, 4, 5, 9, 14 and 15 are compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
+    if (!VR_EXPERIMENTAL_FLAVOURS && (flavour == 2 || flavour == 3 || flavour == 4 || flavour == 5 || flavour == 9 || flavour == 14))
+        return fail(c, VR_ERR_UNSUPPORTED, "vr_set_kernel_flavour: flavours 2, 3, 4, 5, 9 and 14 are compiled with -DVR_EXPERIMENTAL_FLAVOURS=1 only");
     c->flavour = flavour;
     return VR_OK;
 }

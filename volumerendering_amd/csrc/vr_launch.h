@@ -20,17 +20,20 @@
 #include "vr_dp.h"
 #include "vr_pw.h"
 #include "vr_p2.h"
-// Kernel forms that lost every A/B -- flavours 2 / 3 (register-staged LDS wave tiles), 4
+// Kernel forms that lost every A/B (HISTORY 4.4, 4.5, 4.10) -- flavours 2 / 3 (register-staged LDS wave tiles), 4
 // (closed-form leaping), 5 (skipping without runs), 9 (one lane per ray, pipelined corner loads), 14 (lanes per ray chosen per
-// packet), 15 (LDS tiles by LDS-DMA) and layout 2 (gradients on the fly) -- are compiled only with -DVR_EXPERIMENTAL_FLAVOURS=1
+// packet) and layout 2 (gradients on the fly) -- are compiled only with -DVR_EXPERIMENTAL_FLAVOURS=1
 // (VR_EXPERIMENTAL_FLAVOURS=1 in the environment of build.py): half the march kernel instantiations of the shipped library.
 // Without them vr_set_kernel_flavour / vr_set_volume_layout reject those values.
+// Flavour 15 (vr_lt.h: the voxels of a packet's next steps in an LDS tile filled by LDS-DMA -- the north star's "volume in LDS tiles")
+// is part of the shipped library: slower than the two-steps-ahead kernel everywhere measured, selectable with
+// vr_set_kernel_flavour(15) and tested on every box, not a candidate of the measured choice.
 #ifndef VR_EXPERIMENTAL_FLAVOURS
 #define VR_EXPERIMENTAL_FLAVOURS 0
 #endif
+#include "vr_lt.h"
 #if VR_EXPERIMENTAL_FLAVOURS
 #include "vr_mixed.h"
-#include "vr_lt.h"
 #endif
 #if !VR_FUSED && VR_EXPERIMENTAL_FLAVOURS
 #include "vr_wtb.h"
@@ -205,7 +208,6 @@ void launch_mixed(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
 {
     const int variant = L.variant;
-#if VR_EXPERIMENTAL_FLAVOURS
     if (L.lt) {  // LDS tiles (vr_lt.h): lit shader
         const bool skip = B.frame[0].brick_dist != nullptr;
         if (L.off32) {
@@ -217,6 +219,7 @@ void launch_march(const LaunchDesc& L, hipStream_t s, const MarchBatch& B)
         }
         return;
     }
+#if VR_EXPERIMENTAL_FLAVOURS
     if (L.mixed_items) {
         switch (variant) {
         case VR_VARIANT_BASIC: launch_mixed<V_BASIC>(L, s, B); break;
