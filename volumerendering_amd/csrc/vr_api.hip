@@ -904,13 +904,16 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 // (march_p2_kernel: two corner buffers, 3 wavefronts per SIMD at most; with every ray sampling all the time two per
                 // SIMD are faster -- the corner data in flight is many times the L1 either way: noisy air 2.13 -> 2.04 ms)
                 const bool p2 = fl == 16 || fl == 17;
-                unsigned pw_threads = fl == 17 ? 768u : (fl == 16 ? 512u : 1024u);
+                // (the unlit shader's two buffers are 4-byte densities, 101 VGPRs: 4 wavefronts per SIMD -- C2 one frame at a time 0.121 ->
+                // 0.113 ms, thin table 0.255 -> 0.239, four frames per launch 0.070 -> 0.061: tools/experiments/s2h.sh)
+                unsigned pw_threads = fl == 17 ? (variant == VR_VARIANT_BASIC ? 1024u : 768u) : (fl == 16 ? 512u : 1024u);
                 // (launches in flight: the same shape.  Two workgroups of 6 wavefronts do not share a CU -- the second one's wavefronts
                 // would have to go 1-1-2-2 over the SIMDs where the dispatcher deals 2-2-1-1: measured 0.75 ms per C3 frame, what
                 // one such workgroup per CU takes -- and two of 4 run at 8 wavefronts per CU: 0.63 against 0.54; three of 4, the same
                 // 12 wavefronts per CU, take 0.79 ms one frame at a time and 0.62 in flight against 0.55 / 0.51: profiles/r04_p2_launch_shapes.txt)
                 unsigned wg_per_cu = 1;
-                if (p2 && c->p2_threads) pw_threads = c->p2_threads;  // (VR_EXP_P2_THREADS: 64 .. 768)
+                if (p2 && c->p2_threads) pw_threads = c->p2_threads;  // (VR_EXP_P2_THREADS: 64 .. 768; .. 1024 for the unlit shader)
+                if (p2 && variant != VR_VARIANT_BASIC && pw_threads > 768u) pw_threads = 768u;
                 if (p2 && c->p2_wgs) wg_per_cu = c->p2_wgs;           // (VR_EXP_P2_WGS: workgroups per CU the grid is sized for)
                 const unsigned per_wg = pw_threads / 64u;
                 const unsigned items = grid.x * (unsigned)n_frames;
@@ -1277,7 +1280,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     if (const char* e = getenv("VR_EXP_PW_LTF")) c->pw_ltf = atoi(e) != 0;
     if (const char* e = getenv("VR_EXP_P2_THREADS")) {
         const int t = atoi(e);
-        if (t >= 64 && t <= 768 && t % 64 == 0) c->p2_threads = (unsigned)t;
+        if (t >= 64 && t <= 1024 && t % 64 == 0) c->p2_threads = (unsigned)t;
     }
     if (const char* e = getenv("VR_EXP_P2_WGS")) c->p2_wgs = (unsigned)(atoi(e) > 0 && atoi(e) <= 8 ? atoi(e) : 0);
     if (const char* e = getenv("VR_EXP_P2_DYNQ")) c->p2_dynq = atoi(e);

@@ -39,6 +39,7 @@ constexpr int kP2JumpMax = VR_P2_JUMP_MAX;  // identity steps one trip may skip 
 constexpr bool kP2Exit = kApproach && VR_P2_EXIT != 0;  // ... and the same knowledge behind the box of the active bricks (A/B: -DVR_P2_EXIT=0)
 constexpr bool kP2Approach = kApproach;  // the approach loop in front of the pipelined loop (-DVR_APPROACH=0: A/B builds)
 constexpr int kP2Threads = 768;  // at most 12 wavefronts per CU, 3 per SIMD (two corner buffers are 64 of ~168 VGPRs)
+constexpr int kP2ThreadsUnlit = 1024;  // the unlit shader's buffers are 4-byte densities (101 VGPRs): 4 wavefronts per SIMD fit
 
 // (indexed buffer loads -- vr_struct_load_b128 / _b32 -- are declared in vr_kernels.h)
 
@@ -240,7 +241,7 @@ __device__ __forceinline__ bool p2_vote(const MarchParams& P0, bool sampled, flo
 // exposed.  A step in which no ray blends interpolates nothing; the per-step vote (every opacity zero for certain: no texels,
 // no gradient, no shading) is march_packet's.
 template <int V, bool SKIP, bool WIN, bool BATCH>
-__global__ __launch_bounds__(kP2Threads) void march_p2_kernel(const MarchBatch B, const PwQueue Q)
+__global__ __launch_bounds__(V == V_BASIC ? kP2ThreadsUnlit : kP2Threads) void march_p2_kernel(const MarchBatch B, const PwQueue Q)
 {
     static_assert(V == V_LIGHT || V == V_BASIC || (V == V_VOLUME_MASK && SKIP), "lit / unlit shader; the three-volume composite with its brick records");
     constexpr int kSrc = (V == V_VOLUME_MASK) ? 2 : 0;  // the volume that is pipelined: the CT of the composite (VolumeMaskApp.wgsl:187)
