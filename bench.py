@@ -521,6 +521,7 @@ def main():
     sync_all()
 
     last_choice = {}
+    full_choice = []  # [vr_kernel_choice, flavour that ran] behind the last batched launch that carried all its frames
     last_batch = {}  # (buffer set, frame of the launch) -> g of the camera the batched leg rendered into it last
     last_single = {}  # buffer set -> g, one frame per launch
 
@@ -534,6 +535,8 @@ def main():
                     k = min(fpl, end - g)
                     b = launch % nbuf
                     ctx.render_batch_async(variant, [us[(g + j) % n_seq] for j in range(k)], [t.data_ptr() for t in batch_frames[b][:k]], streams[b])
+                    if k == fpl:  # (a last launch with fewer frames is another launch shape, with a measured choice of its own)
+                        full_choice[:] = [ctx.kernel_choice(), ctx.last_kernel_flavour()]
                     for j in range(k):
                         last_batch[(b, j)] = (g + j) % n_seq
                     g += k
@@ -609,9 +612,12 @@ def main():
             sync_all()
         kt = ctx.kernel_times(min(max(n_steps, min_events), 256))
         cands, cms, chosen = ctx.kernel_choice()  # what the default's measured choice knows of this leg's launch shape
+        ran_last = ctx.last_kernel_flavour()
+        if fpl > 1 and not multi and full_choice:
+            (cands, cms, chosen), ran_last = full_choice
         last_choice.clear()
         last_choice.update({"candidates": cands, "ms_per_launch": [round(x, 4) for x in cms], "kept": cands[chosen] if chosen >= 0 else None,
-                            "ran_last": ctx.last_kernel_flavour()})
+                            "ran_last": ran_last})
         if dist is not None:  # MAX over ranks
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
