@@ -132,6 +132,9 @@ struct vr_ctx {
     int n_flight = 0;
     hipStream_t order_stream = nullptr;  // the sorts run here, behind their launch's event: never on a frame's critical path
     int order_mode = 1;  // 0 = launch the blocks in index order (VR_EXP_ORDER=0)
+    // VR_EXP_HOST_ORDER_WAIT=1: one frame at a time, a launch waits for the two sorts it depends on (the launch order it reads, the sort
+    // that read its record slot last) on the HOST, before it is enqueued, instead of on its stream (enqueue_render).  Off by default.
+    int host_order_wait = 0;
     int cnt_buf = 0;                           // the buffer the last launch wrote
     bool cnt_pending = false;                  // block counts of the last launch not summed / copied yet
     int cnt_blocks = 0;
@@ -434,7 +437,9 @@ int tune_pick(vr_ctx* c, unsigned long long key, unsigned long long shape, const
         }
         t->cost[i] = (float)(ticks * 1.0e-5);  // 100 MHz ticks -> ms
         // (another kernel must be 2 % faster than the prior's to replace it: the spans of equal kernels differ by about that much)
-        if (i > 0 && t->cost[i] < t->cost[best] * (best == 0 ? 0.98f : 1.0f)) best = i;
+        // (... with launches in flight by 5 %: a candidate's interior launches still run beside its neighbours' tails -- a trial that
+        // measured march_kernel at 0.407 ms per C3 frame pipelined against 0.418 kept it, and it then ran at 0.467: gpurun_out/s2p)
+        if (i > 0 && t->cost[i] < t->cost[best] * (best == 0 ? (in_flight > 1 ? 0.95f : 0.98f) : 1.0f)) best = i;
     }
     t->choice = best;
     t->chain_ref = chain_now;
@@ -800,9 +805,17 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // the slot's previous launch (kInFlight launches ago, possibly on another stream) must have finished before its
         // record buffer is written again or re-allocated: this is what bounds the launches in flight to kInFlight
         if (c->slot_used[cb]) VR_HIP(c, hipEventSynchronize(c->slot_done[cb]));
+        // A stream's wait for another stream's event costs the stream 5 us per launch even when the event completed long ago
+        // (tools/ubench/stream_gap.hip): the two waits below are 10 of the 17 us between two march kernels of a one-at-a-time loop.
+        // Waiting on the HOST instead (VR_EXP_HOST_ORDER_WAIT=1, callers with vr_hint_frames_in_flight <= 1) buys them back -- C3 0.4685 ->
+        // 0.461 ms per frame, C2 0.113 -> 0.106, C1 0.042 -> 0.035 -- but leaves the host two or three launches ahead of the device instead
+        // of eight, and a host thread that wakes up a few milliseconds late then idles the device (two of sixteen legs on a shared box:
+        // C1 0.040 -> 0.37 ms, C4 0.51 -> 0.64); taking the complete order of eight launches ago keeps the queue deep and loses more
+        // to the stale order than the waits cost (+17 us of span per C3 frame).  tools/experiments/s2o.sh, s2p.sh.  Off by default.
+        const bool host_wait = c->host_order_wait != 0 && c->frames_in_flight <= 1;
         if (c->order_seq >= (unsigned long long)kInFlight) {  // ... and the sort that read those records
             const vr_ctx::OrderSlot& po = c->order_ring[(c->order_seq - kInFlight) % kOrderRing];
-            if (po.valid && po.seq + kInFlight == c->order_seq) VR_HIP(c, hipStreamWaitEvent(s, po.sorted, 0));
+            if (po.valid && po.seq + kInFlight == c->order_seq) VR_HIP(c, host_wait ? hipEventSynchronize(po.sorted) : hipStreamWaitEvent(s, po.sorted, 0));
         }
         // every frame of the launch has its own records; twice the space for one frame: a packet marched as two half packets
         // (vr_mixed.h) leaves its second half's record grid.x records further on
@@ -839,7 +852,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 if (o.valid && o.key == okey && o.seq + age + 1 >= c->order_seq && o.seq + age <= c->order_seq && (!best || o.seq > best->seq))
                     best = &o;
             if (best) {
-                VR_HIP(c, hipStreamWaitEvent(s, best->sorted, 0));
+                VR_HIP(c, host_wait ? hipEventSynchronize(best->sorted) : hipStreamWaitEvent(s, best->sorted, 0));
                 P.order = best->buf;
                 if (fl == 14 && best->has_items && c->h_items) {
                     const int bi = (int)(best - c->order_ring);
@@ -1332,6 +1345,7 @@ int vr_create(vr_ctx** out, uint32_t width, uint32_t height, int device_id)
     else
         c->h_chain = nullptr;  // (the choice of lanes per ray then goes by the launch size alone)
     if (const char* e = getenv("VR_EXP_ORDER")) c->order_mode = atoi(e);
+    if (const char* e = getenv("VR_EXP_HOST_ORDER_WAIT")) c->host_order_wait = atoi(e) != 0;
     if (const char* e = getenv("VR_EXP_NO_ZSKIP")) c->zskip = atoi(e) == 0;
     if (const char* e = getenv("VR_EXP_EVENT_TIMING")) c->event_timing = atoi(e) != 0;
     if (!hip_ok(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)")) return bail(VR_ERR_HIP);
