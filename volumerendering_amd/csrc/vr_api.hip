@@ -813,14 +813,26 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // C1 0.040 -> 0.37 ms, C4 0.51 -> 0.64); taking the complete order of eight launches ago keeps the queue deep and loses more
         // to the stale order than the waits cost (+17 us of span per C3 frame).  tools/experiments/s2o.sh, s2p.sh.  Off by default.
         const bool host_wait = c->host_order_wait != 0 && c->frames_in_flight <= 1;
-        if (c->order_seq >= (unsigned long long)kInFlight) {  // ... and the sort that read those records
+        // ... and the sort that read those records.  Every sort runs on the one order stream, in the order of the launches: when this
+        // launch waits for a YOUNGER sort anyway -- the one whose launch order it takes, below -- that wait covers this one, and a wait
+        // for another stream's event less is 5 us less between two march kernels.  Waited for at once only when the record buffer is
+        // re-allocated (the memset behind the allocation writes it).
+        const vr_ctx::OrderSlot* slot_sort = nullptr;
+        if (c->order_seq >= (unsigned long long)kInFlight) {
             const vr_ctx::OrderSlot& po = c->order_ring[(c->order_seq - kInFlight) % kOrderRing];
-            if (po.valid && po.seq + kInFlight == c->order_seq) VR_HIP(c, host_wait ? hipEventSynchronize(po.sorted) : hipStreamWaitEvent(s, po.sorted, 0));
+            if (po.valid && po.seq + kInFlight == c->order_seq) slot_sort = &po;
         }
+        auto wait_slot_sort = [&]() -> hipError_t {
+            if (!slot_sort) return hipSuccess;
+            const hipError_t e = host_wait ? hipEventSynchronize(slot_sort->sorted) : hipStreamWaitEvent(s, slot_sort->sorted, 0);
+            slot_sort = nullptr;
+            return e;
+        };
         // every frame of the launch has its own records; twice the space for one frame: a packet marched as two half packets
         // (vr_mixed.h) leaves its second half's record grid.x records further on
         const size_t n_records = (size_t)grid.x * (size_t)(n_frames > 1 ? n_frames : 2);
         if (n_records > c->block_counts_cap[cb]) {
+            VR_HIP(c, wait_slot_sort());
             if (c->d_block_counts[cb]) (void)hipFree(c->d_block_counts[cb]);
             c->d_block_counts[cb] = nullptr;
             c->block_counts_cap[cb] = 0;
@@ -853,6 +865,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                     best = &o;
             if (best) {
                 VR_HIP(c, host_wait ? hipEventSynchronize(best->sorted) : hipStreamWaitEvent(s, best->sorted, 0));
+                if (slot_sort && best->seq >= slot_sort->seq) slot_sort = nullptr;  // (covered: the order stream runs its sorts in order)
                 P.order = best->buf;
                 if (fl == 14 && best->has_items && c->h_items) {
                     const int bi = (int)(best - c->order_ring);
@@ -865,6 +878,7 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
                 }
             }
         }
+        VR_HIP(c, wait_slot_sort());
         if (!mixed_items) c->last_split = 0;
         const int slot = (int)(c->ring.head % kRing);
         if (frame_events) VR_HIP(c, hipEventRecord(c->tm.ev_k0, s));
