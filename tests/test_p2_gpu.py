@@ -207,6 +207,38 @@ def test_persistent_launches_in_flight(variant):
                     o.close()
 
 
+@pytest.mark.parametrize("host_wait", ["0", "1"])
+def test_one_frame_at_a_time_on_one_stream_far_ahead_of_the_device(monkeypatch, host_wait):
+    """The stream-ordered loop of bench.py's serial leg: 40 launches enqueued on one stream without waiting for any, four cameras in
+    turn into four buffers -- more launches than record slots (8) and launch-order buffers (16), so every launch takes an earlier
+    launch's order and re-uses a record slot whose sort it must be ordered behind (one wait for the younger of the two sorts; with
+    VR_EXP_HOST_ORDER_WAIT=1 on the host).  Every frame equals its reference, the last launch's counts too; default and forced kernels."""
+    monkeypatch.setenv("VR_EXP_HOST_ORDER_WAIT", host_wait)
+    n, W, H = 24, 640, 360
+    step, count = hr.stepping_params(n, n, n)
+    vols, tfs = vt.scene(capi.LIGHT, n=n)
+    us = [hr.make_uniforms(W, H, steps_count=count, step_size=step, distance=0.9, yaw=0.3 * k) for k in range(4)]
+    with capi.Context(W, H, 0) as ctx:
+        ctx.set_kernel_flavour(6)
+        refs = [vt.gpu_render(ctx, capi.LIGHT, u, vols, tfs) for u in us]
+        outs = [capi.Context(W, H, 0) for _ in range(4)]
+        try:
+            for fl in (0, 17, 6):
+                ctx.set_kernel_flavour(fl)
+                ctx.hint_frames_in_flight(1)
+                for k in range(40):
+                    ctx.set_uniforms(vt.to_capi_uniforms(us[k & 3]))
+                    ctx.render_async(capi.LIGHT, outs[k & 3].frame_device_ptr(), ctx.stream(0))
+                assert ctx.counters()[0] == refs[3][2]   # (waits for the last launch: camera 39 & 3)
+                ctx.resize(W, H)                          # drains the device
+                for k in range(4):
+                    got, _, _ = outs[k].download()
+                    assert np.array_equal(vt.bits(got), vt.bits(refs[k][0])), (fl, k)
+        finally:
+            for o in outs:
+                o.close()
+
+
 # ---- the default's measured kernel choice (flavour 0; csrc/vr_api.hip: tune_pick) -------------------------------------------------
 def test_measured_kernel_choice_settles_and_changes_nothing():
     """Flavour 0 tries the eligible kernel forms in turn on the caller's own frames and keeps the fastest.  Whatever runs, every
