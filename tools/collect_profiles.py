@@ -56,7 +56,7 @@ def main():
     for js in glob.glob(os.path.join(SRC, "pmc_probe_*.json")):
         shutil.copyfile(js, os.path.join(DST, f"r{RND}_" + os.path.basename(js)))
     for txt in glob.glob(os.path.join(SRC, "*.txt")):
-        if os.path.basename(txt).startswith(("block_trace", "valu_issue", "struct_buffer")):
+        if os.path.basename(txt).startswith(("block_trace", "valu_issue", "struct_buffer", "stream_gap", "launch_gap")):
             shutil.copyfile(txt, os.path.join(DST, f"r{RND}_" + os.path.basename(txt)))
     f = newest(os.path.join(SRC, "ubench_pmc", "*", "*counter_collection.csv"))
     if f:

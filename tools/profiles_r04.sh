@@ -37,6 +37,11 @@ python3 tools/block_trace.py --flavour 6 > $OUT/block_trace_c3_f6.txt 2>&1
 python3 tools/block_trace.py --flavour 16 --air noisy > $OUT/block_trace_noisy_f16.txt 2>&1
 python3 tools/block_trace.py --flavour 17 --workload C4 > $OUT/block_trace_c4_f17.txt 2>&1
 ./tools/ubench/struct_buffer > $OUT/struct_buffer.txt 2>&1
+# (hipcc -O3 --offload-arch=gfx950 -o tools/ubench/stream_gap tools/ubench/stream_gap.hip) what a stream pays between two launches
+./tools/ubench/stream_gap > $OUT/stream_gap.txt 2>&1
+# the serial leg over 200 cameras: the last launch's packets, and from a kernel trace the idle time between two march kernels
+python3 tools/launch_gap.py --run > $OUT/launch_gap_c3_f17.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/launch_gap_kt -- python3 $R/tools/launch_gap.py --run > /dev/null 2>&1 && python3 $R/tools/launch_gap.py --read $OUT/launch_gap_kt >> $OUT/launch_gap_c3_f17.txt 2>&1; rm -rf $OUT/launch_gap_kt)
 G="SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES;SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_LDS;SQ_IFETCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC;SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY;SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH"
 python3 tools/pmc_probe.py --flavour 17 --groups "$G" > $OUT/pmc_probe_c3_f17.json 2> $OUT/pmc_probe_c3_f17.err
 python3 tools/pmc_probe.py --flavour 6 --groups "$G" > $OUT/pmc_probe_c3_f6.json 2> $OUT/pmc_probe_c3_f6.err
