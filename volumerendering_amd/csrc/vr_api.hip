@@ -808,10 +808,11 @@ int enqueue_render(vr_ctx* c, int variant, int rank, int world, bool packed, flo
         // A stream's wait for another stream's event costs the stream 5 us per launch even when the event completed long ago
         // (tools/ubench/stream_gap.hip): the two waits below are 10 of the 17 us between two march kernels of a one-at-a-time loop.
         // Waiting on the HOST instead (VR_EXP_HOST_ORDER_WAIT=1, callers with vr_hint_frames_in_flight <= 1) buys them back -- C3 0.4685 ->
-        // 0.461 ms per frame, C2 0.113 -> 0.106, C1 0.042 -> 0.035; with the ONE wait a launch has left (below) 0.467 -> 0.461 -- but leaves the host two or three launches ahead of the device instead
-        // of eight, and a host thread that wakes up a few milliseconds late then idles the device (two of sixteen legs on a shared box:
-        // C1 0.040 -> 0.37 ms, C4 0.51 -> 0.64); taking the complete order of eight launches ago keeps the queue deep and loses more
-        // to the stale order than the waits cost (+17 us of span per C3 frame).  tools/experiments/s2o.sh, s2p.sh.  Off by default.
+        // 0.461 ms per frame, C2 0.113 -> 0.106, C1 0.042 -> 0.035; with the ONE wait a launch has left (below) 0.467 -> 0.461 -- but
+        // leaves the host two or three launches ahead of the device instead of eight, and a host thread that wakes up a few
+        // milliseconds late then idles the device (two of sixteen legs on a shared box: C1 0.040 -> 0.37 ms, C4 0.51 -> 0.64); taking
+        // the complete order of eight launches ago keeps the queue deep and loses more to the stale order than the waits cost (+17 us
+        // of span per C3 frame).  tools/experiments/s2o.sh, s2p.sh.  Off by default.
         const bool host_wait = c->host_order_wait != 0 && c->frames_in_flight <= 1;
         // ... and the sort that read those records.  Every sort runs on the one order stream, in the order of the launches: when this
         // launch waits for a YOUNGER sort anyway -- the one whose launch order it takes, below -- that wait covers this one, and a wait
